@@ -123,6 +123,7 @@ RT_HOST_SYMBOLS = {
     "rth_write_bmp": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_void_p]),
     "rth_read_bmp_size": (C.c_int, [C.c_char_p, PI, PI]),
     "rth_read_bmp": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_void_p]),
+    "rth_abi_sizeof": (C.c_int, [C.c_int]),
 }
 
 

@@ -1,0 +1,1245 @@
+// HIP kernels and C-ABI of the MI355X (gfx950) render path.
+//
+// The reference's recursive RayTracer::traceRay (src/RayTracer.cpp:132-226)
+// runs here as an iterative wavefront over recursion levels.  For one batch of
+// primary samples:
+//
+//   level L = 0 .. depth
+//     k_trace     closest hit of every ray of the level (Scene::intersect)
+//     k_surface   misses -> background colour; hits -> compacted shade points
+//                 (isect reconstruction: N, material, Q)
+//     k_lights    one thread per (light, shade point): shadow ray +
+//                 Light::{distance,shadow}Attenuation + the Phong terms
+//     k_shade     Material::shade's in-order sum over lights, then the
+//                 reflected / refracted rays of the next level, compacted per
+//                 wavefront into the next level's queue
+//   level L = depth .. 0
+//     k_combine   I = shade + kr*I(reflected) + kt*I(refracted), i.e. the
+//                 additions of traceRay in the reference's order
+//   k_resolve     clamp, mean over sub-samples, truncate to RGB8
+//
+// Every ray of a batch owns one slot of a pool; a shade point stores the pool
+// slots of its two children, so the bottom-up pass reproduces the recursion's
+// floating-point evaluation order exactly and is independent of the order in
+// which waves appended to the queues.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/rt_amd.h"
+#include "rt_shade.h"
+
+using namespace rtd;
+
+// ============================================================== device side
+namespace {
+
+constexpr int kBlock = 256;
+
+struct Counters {           // device-resident, zeroed per level / per call
+  unsigned int nsp;         // shade points appended at this level
+  unsigned int nnext;       // rays appended to the next level
+  unsigned int overflow;    // pool exhausted
+  unsigned int _pad;
+  unsigned long long refl, refr, litsp, nodes, prims;
+};
+
+struct Pool {
+  size_t cap;                                    // slots
+  // level-transient, double buffered by level parity
+  double* rayP[2]; double* rayD[2]; int* rayType[2];
+  double* hitT; int* hitPrim;
+  // shade points of the current level (indexed 0..nsp)
+  double* spQ; double* spN; double* spKd; double* spKs; double* spShin; int* spLit; int* spRayLocal;
+  double* lightD; double* lightS;                // [n_lights][3][cap]
+  // persistent for the whole batch (pool slot / pool shade-point index)
+  double* rayI;
+  double* spShade; double* spKr; double* spKt; double* spIor;
+  int* spChildRefl; int* spChildRefr; int* spRayGlobal;
+  int* primaryId;                                // objectID of the level-0 hit per sample
+  Counters* counters;
+};
+
+struct FrameMap {           // pixel slot -> pixel, for tile-ordered rendering
+  int width, height;
+  int tileW, tileH, tilesX;
+  int shardIndex, shardCount;
+  const int* pixelList;     // optional explicit (x,y) list (adaptive AA), else NULL
+  int ns;                   // samples per pixel
+  int aaN;                  // n (ns = n*n) or 0
+  const double* jitter;     // device copy, 2*ns values or NULL
+};
+
+// Pixel slot -> (x, y).  Slots enumerate this shard's tiles in increasing tile
+// number; inside a tile, 8x8 blocks row-major, pixels row-major in the block,
+// so one wavefront works on one 8x8 block.  Slots outside the frame are inactive.
+__device__ __forceinline__ bool slotToPixel(const FrameMap& fm, long long slot, int& x, int& y,
+                                            int& tileK, int& lx, int& ly) {
+  if (fm.pixelList) {
+    x = fm.pixelList[2 * slot];
+    y = fm.pixelList[2 * slot + 1];
+    tileK = 0; lx = ly = 0;
+    return true;
+  }
+  const int per = fm.tileW * fm.tileH;
+  tileK = (int)(slot / per);
+  const int rem = (int)(slot % per);
+  const int t = fm.shardIndex + tileK * fm.shardCount;
+  const int tx = t % fm.tilesX, ty = t / fm.tilesX;
+  const int blk = rem >> 6, in = rem & 63;
+  const int bpr = fm.tileW >> 3;
+  lx = (blk % bpr) * 8 + (in & 7);
+  ly = (blk / bpr) * 8 + (in >> 3);
+  x = tx * fm.tileW + lx;
+  y = ty * fm.tileH + ly;
+  return x < fm.width && y < fm.height;
+}
+
+// Camera::rayThrough for every sample of the batch (camera.cpp:20-31) at the
+// coordinates of tracePixel / tracePixelAntiAlias (RayTracer.cpp:51-52,84-92).
+__global__ void __launch_bounds__(kBlock)
+k_raygen(DevScene S, FrameMap fm, long long firstPixelSlot, int nSamples, Pool P) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nSamples) return;
+  const long long slot = firstPixelSlot + i / fm.ns;
+  const int k = i % fm.ns;
+  int px, py, tk, lx, ly;
+  const bool active = slotToPixel(fm, slot, px, py, tk, lx, ly);
+  if (!active) {
+    P.rayType[0][i] = -1;
+    return;
+  }
+  double x = double(px) / double(fm.width);
+  double y = double(py) / double(fm.height);
+  if (fm.aaN > 0) {
+    const int n = fm.aaN;
+    const double deltaX = (1.0 / double(fm.width)) / n;
+    const double deltaY = (1.0 / double(fm.height)) / n;
+    const int sc = k / n, sr = k % n;   // column outer, row inner (RayTracer.cpp:87-89)
+    const double jx = fm.jitter ? fm.jitter[2 * k] : 0.0, jy = fm.jitter ? fm.jitter[2 * k + 1] : 0.0;
+    x = x + sc * deltaX + jx * deltaX;
+    y = y + sr * deltaY + jy * deltaY;
+  }
+  x -= 0.5;
+  y -= 0.5;
+  const V3 dir = normalized(V3(S.look) + x * V3(S.u) + y * V3(S.v));
+  storeV3(P.rayP[0], P.cap, i, V3(S.eye));
+  storeV3(P.rayD[0], P.cap, i, dir);
+  P.rayType[0][i] = RT_RAY_VISIBILITY;
+}
+
+__device__ __forceinline__ void flushCounters(const TraceCounters& c, Counters* g) {
+  // wave-level sum, one atomic per wavefront
+  unsigned int n = c.nodes, t = c.prims;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    n += __shfl_down(n, off);
+    t += __shfl_down(t, off);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(&g->nodes, (unsigned long long)n);
+    atomicAdd(&g->prims, (unsigned long long)t);
+  }
+}
+
+template <bool FAST, bool STATS>
+__global__ void __launch_bounds__(kBlock)
+k_trace(DevScene S, int n, const double* rayP, const double* rayD, const int* rayType, size_t stride,
+        double* hitT, int* hitPrim, Counters* counters) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  TraceCounters tc{0, 0};
+  if (i < n) {
+    const int type = rayType[i];
+    int prim = RT_PRIM_NONE;
+    double t = 0.0;
+    if (type >= 0) {
+      const V3 p = loadV3(rayP, stride, i), d = loadV3(rayD, stride, i);
+      prim = traceClosest<FAST, STATS>(S, p, d, type, 1.0e308, t, tc);
+    }
+    hitT[i] = t;
+    hitPrim[i] = prim;
+  }
+  if (STATS) flushCounters(tc, counters);
+}
+
+// Append helper: all lanes of the wave that reach it get consecutive indices.
+__device__ __forceinline__ unsigned int waveAppend(bool want, unsigned int* counter) {
+  const unsigned long long mask = __ballot(want);
+  if (!want) return 0xffffffffu;
+  const int lane = threadIdx.x & 63;
+  const unsigned int prefix = __popcll(mask & ((1ull << lane) - 1ull));
+  const int leader = __ffsll((long long)mask) - 1;
+  unsigned int base = 0;
+  if (lane == leader) base = atomicAdd(counter, (unsigned int)__popcll(mask));
+  base = __shfl(base, leader);
+  return base + prefix;
+}
+
+// Misses take the background (RayTracer.cpp:213-224); hits become shade points.
+__global__ void __launch_bounds__(kBlock)
+k_surface(DevScene S, int n, int par, size_t rayOff, size_t spOff, int level, int useCube,
+          int filterWidth, Pool P) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  bool isHit = false;
+  int type = -1, prim = RT_PRIM_NONE;
+  if (i < n) {
+    type = P.rayType[par][i];
+    prim = P.hitPrim[i];
+    isHit = type >= 0 && prim != RT_PRIM_NONE;
+    if (!isHit) {
+      V3 bg(0.0, 0.0, 0.0);
+      if (type >= 0 && useCube) bg = cubeColor(S, loadV3(P.rayD[par], P.cap, i), filterWidth);
+      storeV3(P.rayI, P.cap, rayOff + i, bg);
+      if (level == 0) P.primaryId[i] = 0;
+    }
+  }
+  const unsigned int s = waveAppend(isHit, &P.counters->nsp);
+  if (!isHit) return;
+  if (spOff + s >= P.cap) {
+    P.counters->overflow = 1;
+    return;
+  }
+  const V3 p = loadV3(P.rayP[par], P.cap, i), d = loadV3(P.rayD[par], P.cap, i);
+  const double t = P.hitT[i];
+  Surface sf;
+  MatD m;
+  surfaceAt(S, prim, p, d, type, sf, &m, false);
+  if (level == 0) P.primaryId[i] = sf.objectID;
+  const V3 Q = p + (t * d);                                  // ray::at (ray.h:42-43)
+  const V3 base = m.ke + prod(m.ka, V3(S.ambient));          // material.cpp:46
+  const bool lit = !(iszero(m.kd) && iszero(m.ks));          // material.cpp:50-53
+  storeV3(P.spQ, P.cap, s, Q);
+  storeV3(P.spN, P.cap, s, sf.N);
+  storeV3(P.spKd, P.cap, s, m.kd);
+  storeV3(P.spKs, P.cap, s, m.ks);
+  P.spShin[s] = shininessOf(m);
+  P.spLit[s] = lit ? 1 : 0;
+  P.spRayLocal[s] = i;
+  const size_t g = spOff + s;
+  storeV3(P.spShade, P.cap, g, base);
+  storeV3(P.spKr, P.cap, g, m.kr);
+  storeV3(P.spKt, P.cap, g, m.kt);
+  P.spIor[g] = intensityValue(m.index);                      // Material::index (material.h:217)
+  P.spChildRefl[g] = -1;
+  P.spChildRefr[g] = -1;
+  P.spRayGlobal[g] = (int)(rayOff + i);
+  if (lit) atomicAdd(&P.counters->litsp, 1ull);
+}
+
+// One thread per (light, shade point): shadow ray and the two Phong terms of
+// Material::shade for that light (material.cpp:54-73, light.cpp:14-149).
+template <bool FAST, bool STATS>
+__global__ void __launch_bounds__(kBlock)
+k_lights(DevScene S, long long nMax, Pool P) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned int nsp = P.counters->nsp;
+  TraceCounters tc{0, 0};
+  if (idx < nMax && idx < (long long)nsp * S.n_lights) {
+    const int li = (int)(idx / nsp);
+    const int s = (int)(idx % nsp);
+    if (P.spLit[s]) {
+      const RtLight& l = S.lights[li];
+      const V3 Q = loadV3(P.spQ, P.cap, s), N = loadV3(P.spN, P.cap, s);
+      const V3 color(l.color);
+      V3 atten;
+      V3 L;  // direction to the light as Material::shade normalises it
+      if (l.type == RT_LIGHT_DIRECTIONAL) {
+        const V3 sd = normalized(-V3(l.orientation));
+        L = sd;
+        double th;
+        const int prim = traceClosest<FAST, STATS>(S, Q, sd, RT_RAY_SHADOW, 1.0e308, th, tc);
+        atten = (prim != RT_PRIM_NONE) ? V3(0, 0, 0) : color;
+      } else {
+        const V3 position(l.position);
+        V3 sd = normalized(position - Q);
+        L = normalized(sd);  // getDirection normalises, shade normalises again
+        const double lightDistance = length2(position - Q);
+        double th;
+        // FAST: an occluder beyond the light is irrelevant; bound the search a
+        // little past the light so that the strict < below decides
+        const double limit = FAST ? sqrt(lightDistance) * 1.0000001 + 1e-7 : 1.0e308;
+        const int prim = traceClosest<FAST, STATS>(S, Q, sd, RT_RAY_SHADOW, limit, th, tc);
+        bool occluded = false;
+        V3 kt;
+        if (prim != RT_PRIM_NONE) {
+          const V3 Qh = Q + (th * sd);
+          const double distanceSq = length2(Qh - Q);
+          if (distanceSq < lightDistance) {
+            occluded = true;
+            if ((prim & RT_PRIM_FACE) && S.smooth && S.vmaterials &&
+                S.meshes[S.objects[S.tris[prim & ~RT_PRIM_FACE].owner].mesh].has_vertex_materials) {
+              Surface sf;
+              MatD m;
+              surfaceAt(S, prim, Q, sd, RT_RAY_SHADOW, sf, &m, true);
+              kt = m.kt;
+            } else {
+              const int oi = (prim & RT_PRIM_FACE) ? S.tris[prim & ~RT_PRIM_FACE].owner : prim;
+              kt = V3(S.materials[S.objects[oi].material].kt);
+            }
+          }
+        }
+        if (l.type == RT_LIGHT_POINT) {
+          atten = occluded ? prod(kt, color) : color;
+        } else {
+          sd = sd * -1;
+          const V3 orientation(l.orientation);
+          const double angle = acos(dot(orientation, sd)) * 180 / M_PI;
+          if (angle > l.atten_angle) {
+            atten = V3(0.0, 0.0, 0.0);
+          } else {
+            const double fallFactor = pow(dot(orientation, sd), l.fall_rate);
+            atten = occluded ? prod((color * fallFactor), kt) : (color * fallFactor);
+          }
+        }
+      }
+      const V3 lightIntensity = distanceAttenuation(l, Q) * atten;
+      const V3 kd = loadV3(P.spKd, P.cap, s), ks = loadV3(P.spKs, P.cap, s);
+      const V3 D = prod(kd, lightIntensity) * fmax(dot(N, L), 0.0);
+      V3 Sp(0, 0, 0);
+      if (!iszero(ks)) {
+        const V3 view = normalized(V3(S.eye) - Q);             // material.cpp:66-67
+        const V3 cosVector = N * dot(L, N);
+        const V3 sinVector = cosVector - L;
+        const V3 refl = normalized(cosVector + sinVector);
+        Sp = prod(ks, lightIntensity) * pow(fmax(dot(refl, view), 0.0), P.spShin[s]);
+      }
+      const size_t o = (size_t)li * 3 * P.cap;
+      storeV3(P.lightD + o, P.cap, s, D);
+      storeV3(P.lightS + o, P.cap, s, Sp);
+    }
+  }
+  if (STATS) flushCounters(tc, P.counters);
+}
+
+// In-order light sum of Material::shade, then the secondary rays of
+// RayTracer::traceRay (RayTracer.cpp:152-201).
+__global__ void __launch_bounds__(kBlock)
+k_shade(DevScene S, int nMax, int par, size_t spOff, size_t nextRayOff, int depthLeft, Pool P) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned int nsp = P.counters->nsp;
+  const bool on = s < nMax && (unsigned int)s < nsp;
+  const size_t g = spOff + (on ? s : 0);
+  bool wantRefl = false, wantRefr = false;
+  V3 Q, reflDir, refrDir;
+  if (on) {
+    V3 I = loadV3(P.spShade, P.cap, g);
+    if (P.spLit[s]) {
+      const bool hasKd = !iszero(loadV3(P.spKd, P.cap, s)), hasKs = !iszero(loadV3(P.spKs, P.cap, s));
+      for (int li = 0; li < S.n_lights; li++) {
+        const size_t o = (size_t)li * 3 * P.cap;
+        if (hasKd) I = I + loadV3(P.lightD + o, P.cap, s);
+        if (hasKs) I = I + loadV3(P.lightS + o, P.cap, s);
+      }
+      storeV3(P.spShade, P.cap, g, I);
+    }
+    if (depthLeft > 0) {
+      const int ri = P.spRayLocal[s];
+      const V3 d = loadV3(P.rayD[par], P.cap, ri);
+      const V3 N = loadV3(P.spN, P.cap, s);
+      const V3 kr = loadV3(P.spKr, P.cap, g), kt = loadV3(P.spKt, P.cap, g);
+      Q = loadV3(P.spQ, P.cap, s);
+      const V3 minusD = -1 * d;
+      const V3 cosVector = N * dot(minusD, N);
+      const V3 sinVector = cosVector + d;
+      if (!iszero(kr)) {
+        reflDir = normalized(cosVector + sinVector);
+        wantRefl = true;
+      }
+      if (!iszero(kt)) {
+        const double cosineAngle = acos(dot(N, d)) * 180 / M_PI;
+        double n_i, n_r;
+        int iDirection;
+        if (cosineAngle > 90) { n_i = 1; n_r = P.spIor[g]; iDirection = 1; }
+        else { n_i = P.spIor[g]; n_r = 1; iDirection = -1; }
+        const V3 sinT = (n_i / n_r) * sinVector;
+        const V3 cosT = (-1 * N) * sqrt(1 - dot(sinT, sinT));
+        if (cosineAngle < 360) {  // RayTracer.cpp:173,195: false only for a NaN angle
+          const V3 rd = normalized(cosT + (double)iDirection * sinT);
+          refrDir = (double)iDirection * rd;
+          wantRefr = true;
+        }
+      }
+    }
+  }
+  const int np = par ^ 1;
+  const unsigned int a = waveAppend(wantRefl, &P.counters->nnext);
+  if (wantRefl) {
+    if (nextRayOff + a >= P.cap) {
+      P.counters->overflow = 1;
+    } else {
+      storeV3(P.rayP[np], P.cap, a, Q);
+      storeV3(P.rayD[np], P.cap, a, reflDir);
+      P.rayType[np][a] = RT_RAY_REFLECTION;
+      P.spChildRefl[g] = (int)(nextRayOff + a);
+      atomicAdd(&P.counters->refl, 1ull);
+    }
+  }
+  const unsigned int b = waveAppend(wantRefr, &P.counters->nnext);
+  if (wantRefr) {
+    if (nextRayOff + b >= P.cap) {
+      P.counters->overflow = 1;
+    } else {
+      storeV3(P.rayP[np], P.cap, b, Q);
+      storeV3(P.rayD[np], P.cap, b, refrDir);
+      P.rayType[np][b] = RT_RAY_REFRACTION;
+      P.spChildRefr[g] = (int)(nextRayOff + b);
+      atomicAdd(&P.counters->refr, 1ull);
+    }
+  }
+}
+
+// intensity = shade; += kr*traceRay(reflected); += kt*traceRay(refracted)
+__global__ void __launch_bounds__(kBlock)
+k_combine(size_t spOff, int nsp, Pool P) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= nsp) return;
+  const size_t g = spOff + s;
+  V3 I = loadV3(P.spShade, P.cap, g);
+  const int cr = P.spChildRefl[g], ct = P.spChildRefr[g];
+  if (cr >= 0) I = I + prod(loadV3(P.spKr, P.cap, g), loadV3(P.rayI, P.cap, (size_t)cr));
+  if (ct >= 0) I = I + prod(loadV3(P.spKt, P.cap, g), loadV3(P.rayI, P.cap, (size_t)ct));
+  storeV3(P.rayI, P.cap, (size_t)P.spRayGlobal[g], I);
+}
+
+// RayTracer::trace's clamp, tracePixel / tracePixelAntiAlias's byte conversion
+// (RayTracer.cpp:41,58-60,94-101).  tileOffset: packed-buffer pixel offset of
+// each of this shard's tiles, or NULL for a full-frame destination.
+__global__ void __launch_bounds__(kBlock)
+k_resolve(FrameMap fm, long long firstPixelSlot, int nPixels, Pool P, unsigned char* rgb, int* hitId,
+          const long long* tileOffset, const int* listIndex) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nPixels) return;
+  const long long slot = firstPixelSlot + i;
+  int px, py, tk, lx, ly;
+  if (!slotToPixel(fm, slot, px, py, tk, lx, ly)) return;
+  V3 col(0, 0, 0);
+  for (int k = 0; k < fm.ns; k++) {
+    V3 c = loadV3(P.rayI, P.cap, (size_t)i * fm.ns + k);
+    if (c.x < 0) c.x = 0.0;
+    if (c.x > 1) c.x = 1.0;
+    if (c.y < 0) c.y = 0.0;
+    if (c.y > 1) c.y = 1.0;
+    if (c.z < 0) c.z = 0.0;
+    if (c.z > 1) c.z = 1.0;
+    if (fm.aaN > 0) col = V3(col.x + c.x, col.y + c.y, col.z + c.z);
+    else col = c;
+  }
+  if (fm.aaN > 0) {
+    const double nn = double(fm.aaN * fm.aaN);
+    col = V3(col.x / nn, col.y / nn, col.z / nn);
+  }
+  size_t o;
+  if (tileOffset) {
+    const int t = fm.shardIndex + tk * fm.shardCount;
+    const int tx = t % fm.tilesX;
+    const int wt = min(fm.tileW, fm.width - tx * fm.tileW);
+    o = (size_t)tileOffset[tk] + (size_t)ly * wt + lx;
+  } else {
+    o = (size_t)px + (size_t)py * fm.width;
+  }
+  (void)listIndex;
+  // (int)(255.0*c) then narrowing to a byte; a NaN converts to 0 here and to
+  // INT_MIN -> byte 0 on the reference's x86-64
+  rgb[3 * o + 0] = (unsigned char)(int)(255.0 * col.x);
+  rgb[3 * o + 1] = (unsigned char)(int)(255.0 * col.y);
+  rgb[3 * o + 2] = (unsigned char)(int)(255.0 * col.z);
+  if (hitId) hitId[o] = P.primaryId[(size_t)i * fm.ns];
+}
+
+// Scene::intersect seam for tests: full isect of n rays.
+template <bool FAST>
+__global__ void __launch_bounds__(kBlock)
+k_intersect(DevScene S, int n, const double* rays, const int* types, RtHit* hits) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const V3 p(rays + 6 * (size_t)i), d(rays + 6 * (size_t)i + 3);
+  const int type = types ? types[i] : RT_RAY_VISIBILITY;
+  TraceCounters tc{0, 0};
+  double t;
+  const int prim = traceClosest<FAST, false>(S, p, d, type, 1.0e308, t, tc);
+  RtHit h;
+  h.t = 1000.0;                      // scene.cpp:155
+  h.N[0] = h.N[1] = h.N[2] = 0.0;
+  h.bary[0] = h.bary[1] = h.bary[2] = 0.0;
+  h.object_id = 0;
+  h._pad = 0;
+  if (prim != RT_PRIM_NONE) {
+    Surface sf;
+    surfaceAt(S, prim, p, d, type, sf, nullptr, false);
+    h.t = t;
+    h.N[0] = sf.N.x; h.N[1] = sf.N.y; h.N[2] = sf.N.z;
+    h.bary[0] = sf.bary.x; h.bary[1] = sf.bary.y; h.bary[2] = sf.bary.z;
+    h.object_id = sf.objectID;
+  }
+  hits[i] = h;
+}
+
+// Packed tiles -> full frame
+__global__ void __launch_bounds__(kBlock)
+k_unpack(const unsigned char* packed, int bpp, FrameMap fm, const long long* tileOffset, int nTiles,
+         unsigned char* frame) {
+  const long long slot = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (slot >= (long long)nTiles * fm.tileW * fm.tileH) return;
+  int px, py, tk, lx, ly;
+  if (!slotToPixel(fm, slot, px, py, tk, lx, ly)) return;
+  const int t = fm.shardIndex + tk * fm.shardCount;
+  const int tx = t % fm.tilesX;
+  const int wt = min(fm.tileW, fm.width - tx * fm.tileW);
+  const size_t src = (size_t)tileOffset[tk] + (size_t)ly * wt + lx;
+  const size_t dst = (size_t)px + (size_t)py * fm.width;
+  for (int b = 0; b < bpp; b++) frame[dst * bpp + b] = packed[src * bpp + b];
+}
+
+// GraphicalUI::applyFilter (ui/GraphicalUI.cpp:437-486) on the device: one
+// thread per pixel.  Column == width reads the next row's first pixel like the
+// reference; anything past the end of the image reads as 0.
+__global__ void __launch_bounds__(kBlock)
+k_edge_mask(const unsigned char* rgb, int w, int h, int cutOff, unsigned char* mask) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= w * h) return;
+  const int r = i / w, c = i % w;
+  const int kernel[9] = {0, 1, 0, 1, -4, 1, 0, 1, 0};
+  double sum = 0;
+  for (int fr = 0; fr < 3; fr++)
+    for (int fc = 0; fc < 3; fc++) {
+      const int tr = r - 1 + fr, tc = c - 1 + fc;
+      if (tr < 0 || tc < 0 || tr > h || tc > w) continue;
+      const long long idx = (long long)tr * w + tc;
+      double g = 0;
+      if (idx < (long long)w * h) {
+        const unsigned char* p = rgb + 3 * idx;
+        g = (double)(unsigned char)(0.299 * p[0] + 0.587 * p[1] + 0.114 * p[2]);
+      }
+      sum = sum + kernel[3 * fr + fc] * g;
+    }
+  mask[i] = (sum > cutOff) ? 255 : 0;
+}
+
+}  // namespace
+
+// ================================================================ host side
+namespace {
+
+thread_local std::string g_lastError;
+
+int fail(int code, const std::string& msg) {
+  g_lastError = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                        \
+  do {                                                                                       \
+    hipError_t _e = (expr);                                                                  \
+    if (_e != hipSuccess)                                                                    \
+      return fail(RT_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e));         \
+  } while (0)
+
+template <class T>
+hipError_t upload(const T* host, size_t count, T** dev) {
+  *dev = nullptr;
+  if (count == 0) return hipSuccess;
+  hipError_t e = hipMalloc((void**)dev, count * sizeof(T));
+  if (e != hipSuccess) return e;
+  return hipMemcpy(*dev, host, count * sizeof(T), hipMemcpyHostToDevice);
+}
+
+inline int gridFor(long long n) { return (int)((n + kBlock - 1) / kBlock); }
+
+}  // namespace
+
+struct RtScene {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  DevScene dev;
+  std::vector<void*> allocs;       // scene arrays
+  int nLights = 0;
+  int maxStackNeed = 0;
+  // workspace
+  Pool pool;
+  std::vector<void*> poolAllocs;
+  size_t poolLights = 0;
+  unsigned char* frameRgb = nullptr; int* frameHit = nullptr; size_t framePixels = 0;
+  long long* tileOffsets = nullptr; size_t tileOffsetsCap = 0;
+  double* jitterDev = nullptr; size_t jitterCap = 0;
+  std::vector<hipEvent_t> events;  // pairs around traversal kernels
+  size_t eventsUsed = 0;
+  hipEvent_t evStart = nullptr, evStop = nullptr;
+
+  ~RtScene() {
+    if (stream) hipStreamSynchronize(stream);
+    for (void* p : allocs) hipFree(p);
+    freePool();
+    if (frameRgb) hipFree(frameRgb);
+    if (frameHit) hipFree(frameHit);
+    if (tileOffsets) hipFree(tileOffsets);
+    if (jitterDev) hipFree(jitterDev);
+    for (hipEvent_t e : events) hipEventDestroy(e);
+    if (evStart) hipEventDestroy(evStart);
+    if (evStop) hipEventDestroy(evStop);
+    if (stream) hipStreamDestroy(stream);
+  }
+  void freePool() {
+    for (void* p : poolAllocs) hipFree(p);
+    poolAllocs.clear();
+    pool.cap = 0;
+  }
+};
+
+namespace {
+
+// Depth of a subtree and validation of child / item indices.
+int treeDepth(const RtSceneDesc& d, int root, int itemLimit, std::string& err) {
+  if (root < 0) return 0;
+  int best = 0;
+  std::vector<std::pair<int, int>> st{{root, 1}};
+  size_t visited = 0;
+  while (!st.empty()) {
+    auto [n, dep] = st.back();
+    st.pop_back();
+    if (n < 0 || n >= d.n_nodes) { err = "kd node index out of range"; return -1; }
+    if (++visited > (size_t)d.n_nodes) { err = "kd tree has a cycle"; return -1; }
+    best = std::max(best, dep);
+    const int l = d.node_left[n], r = d.node_right[n];
+    if (l < 0 && r < 0) {
+      const int s = d.node_item_start[n], c = d.node_item_count[n];
+      if (c < 0 || s < 0 || s + c > d.n_leaf_items) { err = "kd leaf item range out of bounds"; return -1; }
+      for (int k = 0; k < c; k++)
+        if (d.leaf_items[s + k] < 0 || d.leaf_items[s + k] >= itemLimit) {
+          err = "kd leaf item out of range";
+          return -1;
+        }
+    } else {
+      if (l < 0 || r < 0) { err = "kd node with a single child"; return -1; }
+      if (d.node_dim[n] < 0 || d.node_dim[n] > 2) { err = "kd node with bad split dimension"; return -1; }
+      st.push_back({l, dep + 1});
+      st.push_back({r, dep + 1});
+    }
+  }
+  return best;
+}
+
+int ensurePool(RtScene* sc, size_t cap) {
+  const size_t nl = (size_t)std::max(1, sc->nLights);
+  if (sc->pool.cap >= cap && sc->poolLights >= nl) return RT_OK;
+  sc->freePool();
+  Pool& P = sc->pool;
+  auto A = [&](size_t bytes, void** out) -> hipError_t {
+    hipError_t e = hipMalloc(out, bytes);
+    if (e == hipSuccess) sc->poolAllocs.push_back(*out);
+    return e;
+  };
+#define POOL_ALLOC(field, type, count) HIP_TRY(A(sizeof(type) * (count), (void**)&(field)))
+  for (int b = 0; b < 2; b++) {
+    POOL_ALLOC(P.rayP[b], double, 3 * cap);
+    POOL_ALLOC(P.rayD[b], double, 3 * cap);
+    POOL_ALLOC(P.rayType[b], int, cap);
+  }
+  POOL_ALLOC(P.hitT, double, cap);
+  POOL_ALLOC(P.hitPrim, int, cap);
+  POOL_ALLOC(P.spQ, double, 3 * cap);
+  POOL_ALLOC(P.spN, double, 3 * cap);
+  POOL_ALLOC(P.spKd, double, 3 * cap);
+  POOL_ALLOC(P.spKs, double, 3 * cap);
+  POOL_ALLOC(P.spShin, double, cap);
+  POOL_ALLOC(P.spLit, int, cap);
+  POOL_ALLOC(P.spRayLocal, int, cap);
+  POOL_ALLOC(P.lightD, double, nl * 3 * cap);
+  POOL_ALLOC(P.lightS, double, nl * 3 * cap);
+  POOL_ALLOC(P.rayI, double, 3 * cap);
+  POOL_ALLOC(P.spShade, double, 3 * cap);
+  POOL_ALLOC(P.spKr, double, 3 * cap);
+  POOL_ALLOC(P.spKt, double, 3 * cap);
+  POOL_ALLOC(P.spIor, double, cap);
+  POOL_ALLOC(P.spChildRefl, int, cap);
+  POOL_ALLOC(P.spChildRefr, int, cap);
+  POOL_ALLOC(P.spRayGlobal, int, cap);
+  POOL_ALLOC(P.primaryId, int, cap);
+  POOL_ALLOC(P.counters, Counters, 1);
+#undef POOL_ALLOC
+  P.cap = cap;
+  sc->poolLights = nl;
+  return RT_OK;
+}
+
+size_t poolBytesPerSlot(int nLights) {
+  const size_t nl = (size_t)std::max(1, nLights);
+  return 2 * (48 + 4) + 12 + 24 * 4 + 8 + 4 + 4 + nl * 48 + 24 * 4 + 8 + 4 * 4;
+}
+
+struct TileLayout {
+  int tilesX = 0, tilesY = 0, nTiles = 0;       // of this shard
+  std::vector<long long> offsets;                // packed pixel offset per shard tile
+  long long pixels = 0;
+};
+
+TileLayout tileLayout(int w, int h, int tw, int th, int shardIndex, int shardCount) {
+  TileLayout L;
+  L.tilesX = (w + tw - 1) / tw;
+  L.tilesY = (h + th - 1) / th;
+  const int total = L.tilesX * L.tilesY;
+  for (int t = shardIndex; t < total; t += shardCount) {
+    const int tx = t % L.tilesX, ty = t / L.tilesX;
+    const int wt = std::min(tw, w - tx * tw), ht = std::min(th, h - ty * th);
+    L.offsets.push_back(L.pixels);
+    L.pixels += (long long)wt * ht;
+    L.nTiles++;
+  }
+  return L;
+}
+
+struct LevelInfo { size_t rayOff, spOff; int n, nsp; };
+
+struct RenderCtx {
+  RtScene* sc;
+  const RtRenderParams* rp;
+  FrameMap fm;
+  unsigned char* rgbDev;
+  int* hitDev;
+  const long long* tileOffDev;
+  RtStats stats;
+  bool fast, wantStats;
+};
+
+template <bool FAST, bool STATS>
+void launchTrace(RtScene* sc, int n, int par) {
+  Pool& P = sc->pool;
+  k_trace<FAST, STATS><<<gridFor(n), kBlock, 0, sc->stream>>>(
+      sc->dev, n, P.rayP[par], P.rayD[par], P.rayType[par], P.cap, P.hitT, P.hitPrim, P.counters);
+}
+template <bool FAST, bool STATS>
+void launchLights(RtScene* sc, long long nMax) {
+  k_lights<FAST, STATS><<<gridFor(nMax), kBlock, 0, sc->stream>>>(sc->dev, nMax, sc->pool);
+}
+
+bool timedBegin(RtScene* sc) {
+  if (sc->eventsUsed + 2 > sc->events.size()) {
+    for (int k = 0; k < 64; k++) {
+      hipEvent_t e;
+      if (hipEventCreate(&e) != hipSuccess) return false;
+      sc->events.push_back(e);
+    }
+  }
+  hipEventRecord(sc->events[sc->eventsUsed], sc->stream);
+  return true;
+}
+void timedEnd(RtScene* sc) {
+  hipEventRecord(sc->events[sc->eventsUsed + 1], sc->stream);
+  sc->eventsUsed += 2;
+}
+
+// Renders pixel slots [first, first+count) of the frame map.  Returns
+// RT_OK, an error, or +1 when the ray pool overflowed (caller splits the batch).
+int renderBatch(RenderCtx& cx, long long first, int count) {
+  RtScene* sc = cx.sc;
+  Pool& P = sc->pool;
+  const RtRenderParams& rp = *cx.rp;
+  const int ns = cx.fm.ns;
+  const long long nSamples = (long long)count * ns;
+  if ((size_t)nSamples > P.cap) return 1;
+  std::vector<LevelInfo> levels;
+  int n = (int)nSamples, par = 0;
+  size_t rayOff = 0, spOff = 0;
+  unsigned long long litTotal = 0, nodes = 0, prims = 0, refl = 0, refr = 0;
+  k_raygen<<<gridFor(n), kBlock, 0, sc->stream>>>(sc->dev, cx.fm, first, n, P);
+  for (int level = 0; level <= rp.depth && n > 0; level++) {
+    HIP_TRY(hipMemsetAsync(P.counters, 0, sizeof(Counters), sc->stream));
+    const bool timed = timedBegin(sc);
+    if (cx.fast) { if (cx.wantStats) launchTrace<true, true>(sc, n, par); else launchTrace<true, false>(sc, n, par); }
+    else { if (cx.wantStats) launchTrace<false, true>(sc, n, par); else launchTrace<false, false>(sc, n, par); }
+    if (timed) timedEnd(sc);
+    cx.stats.trace_launches++;
+    k_surface<<<gridFor(n), kBlock, 0, sc->stream>>>(sc->dev, n, par, rayOff, spOff, level,
+                                                     rp.use_cubemap && sc->dev.cube_w > 0,
+                                                     rp.filter_width, P);
+    const long long lightThreads = (long long)n * sc->dev.n_lights;
+    if (lightThreads > 0) {
+      const bool timed2 = timedBegin(sc);
+      if (cx.fast) { if (cx.wantStats) launchLights<true, true>(sc, lightThreads); else launchLights<true, false>(sc, lightThreads); }
+      else { if (cx.wantStats) launchLights<false, true>(sc, lightThreads); else launchLights<false, false>(sc, lightThreads); }
+      if (timed2) timedEnd(sc);
+      cx.stats.trace_launches++;
+    }
+    k_shade<<<gridFor(n), kBlock, 0, sc->stream>>>(sc->dev, n, par, spOff, rayOff + n,
+                                                   rp.depth - level, P);
+    Counters c;
+    HIP_TRY(hipMemcpyAsync(&c, P.counters, sizeof c, hipMemcpyDeviceToHost, sc->stream));
+    HIP_TRY(hipStreamSynchronize(sc->stream));
+    if (c.overflow) return 1;
+    levels.push_back({rayOff, spOff, n, (int)c.nsp});
+    litTotal += c.litsp;
+    nodes += c.nodes;
+    prims += c.prims;
+    refl += c.refl;
+    refr += c.refr;
+    rayOff += n;
+    spOff += c.nsp;
+    n = (int)c.nnext;
+    par ^= 1;
+  }
+  for (int li = (int)levels.size() - 1; li >= 0; li--) {
+    const LevelInfo& L = levels[li];
+    if (L.nsp > 0) k_combine<<<gridFor(L.nsp), kBlock, 0, sc->stream>>>(L.spOff, L.nsp, P);
+  }
+  k_resolve<<<gridFor(count), kBlock, 0, sc->stream>>>(cx.fm, first, count, P, cx.rgbDev, cx.hitDev,
+                                                       cx.tileOffDev, nullptr);
+  HIP_TRY(hipGetLastError());
+  // stats: dead (out-of-frame) slots are not rays
+  cx.stats.rays_reflect += refl;
+  cx.stats.rays_refract += refr;
+  cx.stats.rays_shadow += litTotal * (unsigned long long)sc->dev.n_lights;
+  cx.stats.nodes_visited += nodes;
+  cx.stats.prims_tested += prims;
+  for (const LevelInfo& L : levels) cx.stats.shade_points += (unsigned long long)L.nsp;
+  cx.stats.batches++;
+  return RT_OK;
+}
+
+int renderRange(RenderCtx& cx, long long first, long long count, long long batch) {
+  for (long long b = first; b < first + count; b += batch) {
+    const int c = (int)std::min(batch, first + count - b);
+    int rc = renderBatch(cx, b, c);
+    if (rc == 1) {
+      if (c <= 64) return fail(RT_ERR_NOMEM, "ray pool too small for a 64-pixel batch");
+      HIP_TRY(hipStreamSynchronize(cx.sc->stream));
+      rc = renderRange(cx, b, c, std::max<long long>(64, (c / 2 + 63) / 64 * 64));
+    }
+    if (rc != RT_OK) return rc;
+  }
+  return RT_OK;
+}
+
+size_t workspaceBudgetBytes() {
+  size_t mb = 12288;
+  if (const char* e = std::getenv("RT_AMD_WORKSPACE_MB")) {
+    long v = std::atol(e);
+    if (v >= 64) mb = (size_t)v;
+  }
+  size_t freeB = 0, totalB = 0;
+  if (hipMemGetInfo(&freeB, &totalB) == hipSuccess && freeB > 0)
+    mb = std::min(mb, (freeB / (1024 * 1024)) * 3 / 4);
+  return mb * 1024 * 1024;
+}
+
+}  // namespace
+
+// ================================================================== C-ABI
+extern "C" {
+
+int rt_abi_version(void) { return RT_AMD_ABI_VERSION; }
+
+const char* rt_last_error(void) { return g_lastError.c_str(); }
+
+int rt_scene_create(const RtSceneDesc* d, RtScene** out) {
+  if (!d || !out) return fail(RT_ERR_INVALID, "null argument");
+  *out = nullptr;
+  if (d->abi_version != RT_AMD_ABI_VERSION) return fail(RT_ERR_INVALID, "ABI version mismatch");
+  if (d->n_objects < 0 || d->n_lights < 0 || d->n_meshes < 0 || d->n_faces < 0 || d->n_nodes < 0 ||
+      d->n_materials < 0 || d->n_vertices < 0 || d->n_leaf_items < 0)
+    return fail(RT_ERR_INVALID, "negative count in scene description");
+  // ---- validate indices so that no kernel can read out of bounds
+  for (int i = 0; i < d->n_objects; i++) {
+    const RtObject& o = d->objects[i];
+    if (o.kind < RT_OBJ_SPHERE || o.kind > RT_OBJ_TRIMESH) return fail(RT_ERR_INVALID, "bad object kind");
+    if (o.material < 0 || o.material >= d->n_materials) return fail(RT_ERR_INVALID, "object material out of range");
+    if (o.kind == RT_OBJ_TRIMESH && (o.mesh < 0 || o.mesh >= d->n_meshes))
+      return fail(RT_ERR_INVALID, "object mesh index out of range");
+  }
+  for (int i = 0; i < d->n_lights; i++)
+    if (d->lights[i].type < RT_LIGHT_DIRECTIONAL || d->lights[i].type > RT_LIGHT_SPOT)
+      return fail(RT_ERR_INVALID, "bad light type");
+  std::string err;
+  int sceneDepth = 0, meshDepth = 0;
+  if (d->use_kdtree && d->scene_kd_root >= 0) {
+    sceneDepth = treeDepth(*d, d->scene_kd_root, d->n_objects, err);
+    if (sceneDepth < 0) return fail(RT_ERR_INVALID, err);
+  }
+  for (int m = 0; m < d->n_meshes; m++) {
+    const RtMesh& M = d->meshes[m];
+    if (M.object < 0 || M.object >= d->n_objects || d->objects[M.object].mesh != m)
+      return fail(RT_ERR_INVALID, "mesh/object cross reference broken");
+    if (M.first_vertex < 0 || M.n_vertices < 0 || M.first_vertex + M.n_vertices > d->n_vertices ||
+        M.first_face < 0 || M.n_faces < 0 || M.first_face + M.n_faces > d->n_faces)
+      return fail(RT_ERR_INVALID, "mesh vertex/face range out of bounds");
+    if (M.has_vertex_normals && !d->vnormals) return fail(RT_ERR_INVALID, "vertex normals missing");
+    if (M.has_vertex_materials && !d->vmaterials) return fail(RT_ERR_INVALID, "vertex materials missing");
+    for (int f = 0; f < M.n_faces; f++)
+      for (int k = 0; k < 3; k++) {
+        const int id = d->faces[M.first_face + f].ids[k];
+        if (id < 0 || id >= M.n_vertices) return fail(RT_ERR_INVALID, "face vertex index out of range");
+      }
+    if (M.has_vertex_materials)
+      for (int v = 0; v < M.n_vertices; v++) {
+        const int mi = d->vmaterials[M.first_vertex + v];
+        if (mi < 0 || mi >= d->n_materials) return fail(RT_ERR_INVALID, "vertex material out of range");
+      }
+    if (d->use_kdtree && M.kd_root >= 0) {
+      // leaf items of a mesh tree must be faces of that mesh
+      int dep = treeDepth(*d, M.kd_root, d->n_faces, err);
+      if (dep < 0) return fail(RT_ERR_INVALID, err);
+      meshDepth = std::max(meshDepth, dep);
+    }
+  }
+  if (sceneDepth + meshDepth + 4 > RT_STACK_DEPTH)
+    return fail(RT_ERR_UNSUPPORTED, "kd trees deeper than the traversal stack allows");
+
+  std::unique_ptr<RtScene> sc(new RtScene);
+  std::memset(&sc->dev, 0, sizeof sc->dev);
+  std::memset(&sc->pool, 0, sizeof sc->pool);
+  HIP_TRY(hipGetDevice(&sc->device));
+  HIP_TRY(hipStreamCreateWithFlags(&sc->stream, hipStreamNonBlocking));
+  HIP_TRY(hipEventCreate(&sc->evStart));
+  HIP_TRY(hipEventCreate(&sc->evStop));
+  DevScene& D = sc->dev;
+  auto keep = [&](void* p) { if (p) sc->allocs.push_back(p); };
+
+  // nodes
+  {
+    std::vector<DevNode> nodes((size_t)d->n_nodes);
+    for (int n = 0; n < d->n_nodes; n++) {
+      DevNode& N = nodes[n];
+      N.split = d->node_split[n];
+      if (d->node_left[n] < 0 && d->node_right[n] < 0) {
+        N.a = ((uint32_t)d->node_item_start[n] << 2) | 3u;
+        N.b = (uint32_t)d->node_item_count[n];
+      } else {
+        N.a = ((uint32_t)d->node_left[n] << 2) | (uint32_t)(d->node_dim[n] & 3);
+        N.b = (uint32_t)d->node_right[n];
+      }
+    }
+    DevNode* p; HIP_TRY(upload(nodes.data(), nodes.size(), &p)); keep(p); D.nodes = p;
+    int* it; HIP_TRY(upload(d->leaf_items, (size_t)d->n_leaf_items, &it)); keep(it); D.items = it;
+  }
+  // triangles with the ray-independent terms of TrimeshFace::intersectLocal
+  {
+    std::vector<DevTri> tris((size_t)d->n_faces);
+    std::vector<int> ids((size_t)d->n_faces * 3);
+    for (int m = 0; m < d->n_meshes; m++) {
+      const RtMesh& M = d->meshes[m];
+      for (int f = 0; f < M.n_faces; f++) {
+        const int fi = M.first_face + f;
+        const RtFace& F = d->faces[fi];
+        DevTri& T = tris[fi];
+        const double* vb = d->vertices + 3 * (size_t)M.first_vertex;
+        for (int k = 0; k < 3; k++) {
+          T.v0[k] = vb[3 * F.ids[0] + k];
+          T.v1[k] = vb[3 * F.ids[1] + k];
+          T.v2[k] = vb[3 * F.ids[2] + k];
+          T.n[k] = F.normal[k];
+          ids[3 * fi + k] = M.first_vertex + F.ids[k];
+        }
+        T.dconst = -(T.v0[0] * T.n[0] + T.v0[1] * T.n[1] + T.v0[2] * T.n[2]);
+        const double na0 = std::fabs(T.n[0]), na1 = std::fabs(T.n[1]), na2 = std::fabs(T.n[2]);
+        int ax, ay;
+        if (na0 >= na1 && na0 >= na2) { ax = 1; ay = 2; }
+        else if (na1 >= na0 && na1 >= na2) { ax = 0; ay = 2; }
+        else { ax = 0; ay = 1; }
+        T.axes = ax | (ay << 2);
+        const double z = (T.v1[ax] - T.v0[ax]) * (T.v2[ay] - T.v0[ay]) -
+                         (T.v1[ay] - T.v0[ay]) * (T.v2[ax] - T.v0[ax]);
+        T.abc = std::fabs(z) / 2;
+        T.object_id = F.object_id;
+        T.owner = M.object;
+        T._pad = 0;
+      }
+    }
+    DevTri* p; HIP_TRY(upload(tris.data(), tris.size(), &p)); keep(p); D.tris = p;
+    int* q; HIP_TRY(upload(ids.data(), ids.size(), &q)); keep(q); D.face_ids = q;
+  }
+  { RtObject* p; HIP_TRY(upload(d->objects, (size_t)d->n_objects, &p)); keep(p); D.objects = p; }
+  { RtMesh* p; HIP_TRY(upload(d->meshes, (size_t)d->n_meshes, &p)); keep(p); D.meshes = p; }
+  { RtMaterial* p; HIP_TRY(upload(d->materials, (size_t)d->n_materials, &p)); keep(p); D.materials = p; }
+  { RtLight* p; HIP_TRY(upload(d->lights, (size_t)d->n_lights, &p)); keep(p); D.lights = p; }
+  if (d->vnormals) { double* p; HIP_TRY(upload(d->vnormals, 3 * (size_t)d->n_vertices, &p)); keep(p); D.vnormals = p; }
+  if (d->vmaterials) { int* p; HIP_TRY(upload(d->vmaterials, (size_t)d->n_vertices, &p)); keep(p); D.vmaterials = p; }
+  D.cube_w = D.cube_h = 0;
+  if (d->cube_w > 0 && d->cube_h > 0 && d->cube_rgb[0]) {
+    for (int f = 0; f < 6; f++) {
+      if (!d->cube_rgb[f]) return fail(RT_ERR_INVALID, "cube map needs six faces");
+      unsigned char* p;
+      HIP_TRY(upload(d->cube_rgb[f], (size_t)d->cube_w * d->cube_h * 3, &p));
+      keep(p);
+      D.cube[f] = p;
+    }
+    D.cube_w = d->cube_w;
+    D.cube_h = d->cube_h;
+  }
+  for (int k = 0; k < 3; k++) {
+    D.eye[k] = d->eye[k]; D.look[k] = d->look[k]; D.u[k] = d->u[k]; D.v[k] = d->v[k];
+    D.ambient[k] = d->ambient[k];
+    D.scene_bb_min[k] = d->scene_bb_min[k];
+    D.scene_bb_max[k] = d->scene_bb_max[k];
+  }
+  D.n_objects = d->n_objects;
+  D.n_lights = d->n_lights;
+  D.scene_root = d->scene_kd_root;
+  D.use_kd = d->use_kdtree;
+  D.cull = d->backface_cull;
+  D.smooth = d->smooth_shading;
+  sc->nLights = d->n_lights;
+  *out = sc.release();
+  return RT_OK;
+}
+
+void rt_scene_destroy(RtScene* scene) {
+  if (!scene) return;
+  int cur = 0;
+  hipGetDevice(&cur);
+  hipSetDevice(scene->device);
+  delete scene;
+  hipSetDevice(cur);
+}
+
+long long rt_shard_pixels(int width, int height, int tile_w, int tile_h, int shard_index,
+                          int shard_count) {
+  if (width <= 0 || height <= 0 || tile_w <= 0 || tile_h <= 0 || shard_count <= 0 ||
+      shard_index < 0 || shard_index >= shard_count)
+    return -1;
+  return tileLayout(width, height, tile_w, tile_h, shard_index, shard_count).pixels;
+}
+
+int rt_render(RtScene* sc, const RtRenderParams* rp, unsigned char* rgb8_out, int* hit_id_out,
+              RtStats* stats_out) {
+  if (!sc || !rp || !rgb8_out) return fail(RT_ERR_INVALID, "null argument");
+  if (rp->width <= 0 || rp->height <= 0 || rp->depth < 0) return fail(RT_ERR_INVALID, "bad frame size or depth");
+  if (rp->tile_w <= 0 || rp->tile_h <= 0 || (rp->tile_w & 7) || (rp->tile_h & 7))
+    return fail(RT_ERR_INVALID, "tile_w and tile_h must be positive multiples of 8");
+  if (rp->shard_count <= 0 || rp->shard_index < 0 || rp->shard_index >= rp->shard_count)
+    return fail(RT_ERR_INVALID, "bad shard index/count");
+  if (rp->aa_mode != RT_AA_NONE && (rp->aa_samples < 1 || rp->aa_samples > 8))
+    return fail(RT_ERR_INVALID, "aa_samples must be 1..8");
+  if (rp->aa_mode == RT_AA_ADAPTIVE && (rp->shard_count != 1 || rp->out_is_device))
+    return fail(RT_ERR_UNSUPPORTED, "adaptive anti-aliasing needs the whole frame on one device");
+  if (rp->traversal != RT_TRAVERSE_REFERENCE && rp->traversal != RT_TRAVERSE_FAST)
+    return fail(RT_ERR_INVALID, "bad traversal mode");
+  const auto t0 = std::chrono::steady_clock::now();
+  HIP_TRY(hipSetDevice(sc->device));
+
+  const int w = rp->width, h = rp->height;
+  TileLayout TL = tileLayout(w, h, rp->tile_w, rp->tile_h, rp->shard_index, rp->shard_count);
+  const int nsFull = (rp->aa_mode == RT_AA_NONE) ? 1 : rp->aa_samples * rp->aa_samples;
+
+  // ---- workspace
+  {
+    const size_t perSlot = poolBytesPerSlot(sc->nLights);
+    size_t cap = workspaceBudgetBytes() / perSlot;
+    const long long slots = (long long)TL.nTiles * rp->tile_w * rp->tile_h * nsFull;
+    const size_t want = (size_t)std::max<long long>(slots * 8, 1 << 16);
+    cap = std::min(cap, want);
+    cap = std::min<size_t>(cap, 0x3fffffff);
+    if (rp->max_batch_samples > 0) cap = std::min<size_t>(cap, (size_t)rp->max_batch_samples * 8);
+    cap = std::max<size_t>(cap, 1 << 14);
+    if (sc->pool.cap < cap || sc->pool.cap > 4 * cap) {
+      int rc = ensurePool(sc, cap);
+      if (rc != RT_OK) return rc;
+    }
+  }
+  if (TL.offsets.size() > sc->tileOffsetsCap) {
+    if (sc->tileOffsets) hipFree(sc->tileOffsets);
+    HIP_TRY(hipMalloc((void**)&sc->tileOffsets, TL.offsets.size() * sizeof(long long)));
+    sc->tileOffsetsCap = TL.offsets.size();
+  }
+  if (!TL.offsets.empty())
+    HIP_TRY(hipMemcpyAsync(sc->tileOffsets, TL.offsets.data(), TL.offsets.size() * sizeof(long long),
+                           hipMemcpyHostToDevice, sc->stream));
+  if (nsFull > 1 && rp->jitter) {
+    const size_t need = 2 * (size_t)nsFull;
+    if (need > sc->jitterCap) {
+      if (sc->jitterDev) hipFree(sc->jitterDev);
+      HIP_TRY(hipMalloc((void**)&sc->jitterDev, need * sizeof(double)));
+      sc->jitterCap = need;
+    }
+    HIP_TRY(hipMemcpyAsync(sc->jitterDev, rp->jitter, need * sizeof(double), hipMemcpyHostToDevice, sc->stream));
+  }
+  if (!rp->out_is_device) {
+    const size_t px = (size_t)w * h;
+    if (px > sc->framePixels) {
+      if (sc->frameRgb) hipFree(sc->frameRgb);
+      if (sc->frameHit) hipFree(sc->frameHit);
+      sc->frameRgb = nullptr; sc->frameHit = nullptr; sc->framePixels = 0;
+      HIP_TRY(hipMalloc((void**)&sc->frameRgb, px * 3));
+      HIP_TRY(hipMalloc((void**)&sc->frameHit, px * sizeof(int)));
+      sc->framePixels = px;
+    }
+    HIP_TRY(hipMemsetAsync(sc->frameRgb, 0, px * 3, sc->stream));
+    HIP_TRY(hipMemsetAsync(sc->frameHit, 0, px * sizeof(int), sc->stream));
+  }
+
+  RenderCtx cx;
+  cx.sc = sc;
+  cx.rp = rp;
+  std::memset(&cx.stats, 0, sizeof cx.stats);
+  cx.fast = rp->traversal == RT_TRAVERSE_FAST;
+  cx.wantStats = rp->collect_stats != 0;
+  cx.rgbDev = rp->out_is_device ? rgb8_out : sc->frameRgb;
+  cx.hitDev = rp->out_is_device ? hit_id_out : sc->frameHit;
+  cx.tileOffDev = rp->out_is_device ? sc->tileOffsets : nullptr;
+  FrameMap& fm = cx.fm;
+  fm.width = w; fm.height = h;
+  fm.tileW = rp->tile_w; fm.tileH = rp->tile_h; fm.tilesX = TL.tilesX;
+  fm.shardIndex = rp->shard_index; fm.shardCount = rp->shard_count;
+  fm.pixelList = nullptr;
+  fm.ns = (rp->aa_mode == RT_AA_FULL) ? nsFull : 1;
+  fm.aaN = (rp->aa_mode == RT_AA_FULL) ? rp->aa_samples : 0;
+  fm.jitter = (rp->aa_mode != RT_AA_NONE && rp->jitter) ? sc->jitterDev : nullptr;
+
+  sc->eventsUsed = 0;
+  HIP_TRY(hipEventRecord(sc->evStart, sc->stream));
+  const long long pixelSlots = (long long)TL.nTiles * rp->tile_w * rp->tile_h;
+  auto batchFor = [&](int ns) {
+    // expected growth of a sample into pool slots: a chain per bounce, bounded
+    const long long growth = std::min<long long>((1ll << std::min(rp->depth + 1, 20)) - 1, 6);
+    long long b = (long long)sc->pool.cap / (growth * ns);
+    if (rp->max_batch_samples > 0) b = std::min<long long>(b, rp->max_batch_samples / ns);
+    b = std::max<long long>(64, b / 64 * 64);
+    return b;
+  };
+  int rc = renderRange(cx, 0, pixelSlots, batchFor(fm.ns));
+  if (rc != RT_OK) return rc;
+  cx.stats.rays_primary = (unsigned long long)TL.pixels * fm.ns;
+
+  std::vector<int> flagged;
+  int* listDev = nullptr;
+  if (rp->aa_mode == RT_AA_ADAPTIVE) {
+    // GraphicalUI::doAntiAliasing (ui/GraphicalUI.cpp:377-435): edge mask on the
+    // finished base image, then tracePixelAntiAlias on the flagged pixels only.
+    unsigned char* maskDev = nullptr;
+    HIP_TRY(hipMalloc((void**)&maskDev, (size_t)w * h));
+    k_edge_mask<<<gridFor((long long)w * h), kBlock, 0, sc->stream>>>(sc->frameRgb, w, h, rp->aa_threshold, maskDev);
+    std::vector<unsigned char> mask((size_t)w * h);
+    HIP_TRY(hipMemcpyAsync(mask.data(), maskDev, mask.size(), hipMemcpyDeviceToHost, sc->stream));
+    HIP_TRY(hipStreamSynchronize(sc->stream));
+    hipFree(maskDev);
+    for (int y = 0; y < h; y++)
+      for (int x = 0; x < w; x++)
+        if (mask[(size_t)y * w + x] == 255) { flagged.push_back(x); flagged.push_back(y); }
+    if (!flagged.empty()) {
+      HIP_TRY(hipMalloc((void**)&listDev, flagged.size() * sizeof(int)));
+      HIP_TRY(hipMemcpyAsync(listDev, flagged.data(), flagged.size() * sizeof(int), hipMemcpyHostToDevice, sc->stream));
+      fm.pixelList = listDev;
+      fm.ns = nsFull;
+      fm.aaN = rp->aa_samples;
+      int* keepHit = cx.hitDev;
+      cx.hitDev = nullptr;  // the base pass already recorded the primary hits
+      const long long nFlag = (long long)flagged.size() / 2;
+      rc = renderRange(cx, 0, nFlag, batchFor(fm.ns));
+      cx.hitDev = keepHit;
+      cx.stats.rays_primary += (unsigned long long)nFlag * nsFull;
+      if (rc != RT_OK) { hipFree(listDev); return rc; }
+    }
+  }
+  HIP_TRY(hipEventRecord(sc->evStop, sc->stream));
+
+  if (!rp->out_is_device) {
+    const size_t px = (size_t)w * h;
+    if (rp->shard_count == 1) {
+      HIP_TRY(hipMemcpyAsync(rgb8_out, sc->frameRgb, px * 3, hipMemcpyDeviceToHost, sc->stream));
+      if (hit_id_out) HIP_TRY(hipMemcpyAsync(hit_id_out, sc->frameHit, px * sizeof(int), hipMemcpyDeviceToHost, sc->stream));
+      HIP_TRY(hipStreamSynchronize(sc->stream));
+    } else {
+      // only this shard's pixels may be written in the caller's frame
+      std::vector<unsigned char> tmp(px * 3);
+      std::vector<int> tmpHit(hit_id_out ? px : 0);
+      HIP_TRY(hipMemcpyAsync(tmp.data(), sc->frameRgb, px * 3, hipMemcpyDeviceToHost, sc->stream));
+      if (hit_id_out) HIP_TRY(hipMemcpyAsync(tmpHit.data(), sc->frameHit, px * sizeof(int), hipMemcpyDeviceToHost, sc->stream));
+      HIP_TRY(hipStreamSynchronize(sc->stream));
+      const int total = TL.tilesX * TL.tilesY;
+      for (int t = rp->shard_index; t < total; t += rp->shard_count) {
+        const int tx = t % TL.tilesX, ty = t / TL.tilesX;
+        const int x0 = tx * rp->tile_w, y0 = ty * rp->tile_h;
+        const int x1 = std::min(w, x0 + rp->tile_w), y1 = std::min(h, y0 + rp->tile_h);
+        for (int y = y0; y < y1; y++) {
+          std::memcpy(rgb8_out + ((size_t)y * w + x0) * 3, tmp.data() + ((size_t)y * w + x0) * 3, (size_t)(x1 - x0) * 3);
+          if (hit_id_out) std::memcpy(hit_id_out + (size_t)y * w + x0, tmpHit.data() + (size_t)y * w + x0, (size_t)(x1 - x0) * sizeof(int));
+        }
+      }
+    }
+  } else {
+    HIP_TRY(hipStreamSynchronize(sc->stream));
+  }
+  if (listDev) hipFree(listDev);
+
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, sc->evStart, sc->evStop));
+  cx.stats.ms_device = ms;
+  double traceMs = 0.0;
+  for (size_t e = 0; e + 1 < sc->eventsUsed; e += 2) {
+    float m = 0.f;
+    if (hipEventElapsedTime(&m, sc->events[e], sc->events[e + 1]) == hipSuccess) traceMs += m;
+  }
+  cx.stats.ms_trace = traceMs;
+  cx.stats.ms_total =
+      std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  if (stats_out) *stats_out = cx.stats;
+  return RT_OK;
+}
+
+int rt_intersect_batch(RtScene* sc, int traversal, int n, const double* rays_pd, const int* ray_types,
+                       RtHit* hits) {
+  if (!sc || n < 0 || (n > 0 && (!rays_pd || !hits))) return fail(RT_ERR_INVALID, "bad argument");
+  if (n == 0) return RT_OK;
+  HIP_TRY(hipSetDevice(sc->device));
+  double* r = nullptr; int* ty = nullptr; RtHit* hd = nullptr;
+  HIP_TRY(upload(rays_pd, 6 * (size_t)n, &r));
+  if (ray_types) HIP_TRY(upload(ray_types, (size_t)n, &ty));
+  HIP_TRY(hipMalloc((void**)&hd, (size_t)n * sizeof(RtHit)));
+  if (traversal == RT_TRAVERSE_FAST)
+    k_intersect<true><<<gridFor(n), kBlock, 0, sc->stream>>>(sc->dev, n, r, ty, hd);
+  else
+    k_intersect<false><<<gridFor(n), kBlock, 0, sc->stream>>>(sc->dev, n, r, ty, hd);
+  hipError_t e = hipMemcpyAsync(hits, hd, (size_t)n * sizeof(RtHit), hipMemcpyDeviceToHost, sc->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(sc->stream);
+  hipFree(r);
+  if (ty) hipFree(ty);
+  hipFree(hd);
+  if (e != hipSuccess) return fail(RT_ERR_DEVICE, hipGetErrorString(e));
+  return RT_OK;
+}
+
+int rt_unpack_tiles(const unsigned char* packed_dev, int bytes_per_pixel, int width, int height,
+                    int tile_w, int tile_h, int shard_index, int shard_count,
+                    unsigned char* frame_dev, void* hip_stream) {
+  if (!packed_dev || !frame_dev || bytes_per_pixel <= 0 || width <= 0 || height <= 0 || tile_w <= 0 ||
+      tile_h <= 0 || (tile_w & 7) || (tile_h & 7) || shard_count <= 0 || shard_index < 0 ||
+      shard_index >= shard_count)
+    return fail(RT_ERR_INVALID, "bad argument");
+  TileLayout TL = tileLayout(width, height, tile_w, tile_h, shard_index, shard_count);
+  if (TL.nTiles == 0) return RT_OK;
+  hipStream_t st = (hipStream_t)hip_stream;
+  long long* off = nullptr;
+  HIP_TRY(hipMalloc((void**)&off, TL.offsets.size() * sizeof(long long)));
+  HIP_TRY(hipMemcpyAsync(off, TL.offsets.data(), TL.offsets.size() * sizeof(long long), hipMemcpyHostToDevice, st));
+  FrameMap fm;
+  std::memset(&fm, 0, sizeof fm);
+  fm.width = width; fm.height = height; fm.tileW = tile_w; fm.tileH = tile_h; fm.tilesX = TL.tilesX;
+  fm.shardIndex = shard_index; fm.shardCount = shard_count; fm.ns = 1;
+  const long long slots = (long long)TL.nTiles * tile_w * tile_h;
+  k_unpack<<<gridFor(slots), kBlock, 0, st>>>(packed_dev, bytes_per_pixel, fm, off, TL.nTiles, frame_dev);
+  hipError_t e = hipStreamSynchronize(st);
+  hipFree(off);
+  if (e != hipSuccess) return fail(RT_ERR_DEVICE, hipGetErrorString(e));
+  return RT_OK;
+}
+
+int rt_edge_mask(const unsigned char* rgb8, int width, int height, int cutoff, unsigned char* mask_out) {
+  if (!rgb8 || !mask_out || width <= 0 || height <= 0) return fail(RT_ERR_INVALID, "bad argument");
+  const size_t px = (size_t)width * height;
+  unsigned char *src = nullptr, *dst = nullptr;
+  HIP_TRY(upload(rgb8, px * 3, &src));
+  HIP_TRY(hipMalloc((void**)&dst, px));
+  k_edge_mask<<<gridFor((long long)px), kBlock, 0, 0>>>(src, width, height, cutoff, dst);
+  hipError_t e = hipMemcpy(mask_out, dst, px, hipMemcpyDeviceToHost);
+  hipFree(src);
+  hipFree(dst);
+  if (e != hipSuccess) return fail(RT_ERR_DEVICE, hipGetErrorString(e));
+  return RT_OK;
+}
+
+}  // extern "C"

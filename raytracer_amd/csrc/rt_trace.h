@@ -1,0 +1,553 @@
+// Device-side scene layout, primitive tests and the two-level KD traversal.
+//
+// Closest-hit query = Scene::intersect (src/scene/scene.cpp:133-159).  Two
+// flavours share the primitive arithmetic:
+//   REFERENCE  Scene::intersectKdTree's exact push rules, far child first, no
+//              early exit, per-candidate bounding-box cull through
+//              Geometry::intersect (scene.cpp:59-129,13-36).
+//   FAST       near child first, entries culled once their interval starts
+//              beyond the best hit, intervals kept as outward-rounded floats,
+//              no per-face box cull, barycentric acceptance without divisions.
+// Both compute t of an accepted hit with the same operations, so when they pick
+// the same primitive the hit is bit-identical.
+#pragma once
+#include <stdint.h>
+
+#include "../../include/rt_amd.h"
+#include "rt_math.h"
+
+namespace rtd {
+
+#define RT_EPS 0.00000001  // RAY_EPSILON, src/scene/ray.h:114
+
+// 16-byte KD node.  Internal: a = (left << 2) | dim, b = right.
+// Leaf: a = (first_item << 2) | 3, b = item count.
+struct DevNode {
+  double split;
+  uint32_t a, b;
+};
+
+// 128-byte triangle record = one TrimeshFace (trimesh.h:82-149) with the
+// ray-independent parts of TrimeshFace::intersectLocal hoisted:
+// dconst = -(v0 . n) (trimesh.cpp:122), abc = projected area of the triangle
+// (trimesh.cpp:162), ax/ay = the two kept axes (trimesh.cpp:138-153).
+struct DevTri {
+  double v0[3], v1[3], v2[3];
+  double n[3];
+  double dconst;
+  double abc;
+  int axes;       // ax | (ay << 2)
+  int object_id;  // Geometry::objectID of the face
+  int owner;      // index of the owning Trimesh in objects[]
+  int _pad;
+};
+
+struct DevScene {
+  const DevNode* nodes;
+  const int* items;
+  const DevTri* tris;
+  const int* face_ids;       // 3 global vertex indices per face
+  const RtObject* objects;
+  const RtMesh* meshes;
+  const RtMaterial* materials;
+  const RtLight* lights;
+  const double* vnormals;    // 3 per global vertex
+  const int* vmaterials;     // material index per global vertex
+  const unsigned char* cube[6];
+  int cube_w, cube_h;
+  double eye[3], look[3], u[3], v[3], ambient[3];
+  double scene_bb_min[3], scene_bb_max[3];
+  int n_objects, n_lights, scene_root, use_kd, cull, smooth;
+};
+
+#define RT_PRIM_NONE (-1)
+#define RT_PRIM_FACE 0x40000000  // prim = RT_PRIM_FACE | global face index, else object index
+
+struct TraceCounters { uint32_t nodes, prims; };
+
+// BoundingBox::intersect (src/scene/bbox.h:62-89).  On an early `false` the
+// outputs keep the partial values, which the reference's callers go on to use.
+__device__ __forceinline__ bool boxIntersect(const double* bmin, const double* bmax, const V3& p,
+                                             const V3& d, double& tMin, double& tMax) {
+  tMin = -1.0e308;
+  tMax = 1.0e308;
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    double vd = d.get(a);
+    if (vd == 0.0) continue;
+    double v1 = bmin[a] - p.get(a);
+    double v2 = bmax[a] - p.get(a);
+    double t1 = v1 / vd;
+    double t2 = v2 / vd;
+    if (t1 > t2) { double tt = t1; t1 = t2; t2 = tt; }
+    if (t1 > tMin) tMin = t1;
+    if (t2 < tMax) tMax = t2;
+    if (tMin > tMax) return false;
+    if (tMax < RT_EPS) return false;
+  }
+  return true;
+}
+
+// ------------------------------------------------------------------ primitives
+// Each returns the local-space t and (optionally) the local-space normal of
+// <Primitive>::intersectLocal.
+
+// Sphere.cpp:8-41
+__device__ __forceinline__ bool sphereLocal(const V3& p, const V3& d, double& t, V3& N) {
+  V3 v = -p;
+  double b = dot(v, d);
+  double disc = b * b - dot(v, v) + 1;
+  if (disc < 0.0) return false;
+  disc = sqrt(disc);
+  double t2 = b + disc;
+  if (t2 <= RT_EPS) return false;
+  double t1 = b - disc;
+  t = (t1 > RT_EPS) ? t1 : t2;
+  N = normalized(p + (t * d));
+  return true;
+}
+
+// Box.cpp:11-79
+__device__ __forceinline__ bool boxLocal(const V3& p, const V3& d, double& t, V3& N) {
+  double bestT = 1e100;
+  int bestIndex = -1;
+#pragma unroll
+  for (int it = 0; it < 6; it++) {
+    const int mod0 = it % 3, mod1 = (it + 1) % 3, mod2 = (it + 2) % 3;
+    if (d.get(mod0) == 0) continue;
+    double tt = ((it / 3) - 0.5 - p.get(mod0)) / d.get(mod0);
+    if (tt < RT_EPS || tt > bestT) continue;
+    double x = p.get(mod1) + tt * d.get(mod1);
+    double y = p.get(mod2) + tt * d.get(mod2);
+    if (x <= 0.5 && x >= -0.5 && y <= 0.5 && y >= -0.5) {
+      if (bestT > tt) { bestT = tt; bestIndex = it; }
+    }
+  }
+  if (bestIndex < 0) return false;
+  t = bestT;
+  if (bestIndex < 3)
+    N = V3(-double(bestIndex == 0), -double(bestIndex == 1), -double(bestIndex == 2));
+  else
+    N = V3(double(bestIndex == 3), double(bestIndex == 4), double(bestIndex == 5));
+  return true;
+}
+
+// Square.cpp:9-45
+__device__ __forceinline__ bool squareLocal(const V3& p, const V3& d, double& t, V3& N) {
+  if (d.z == 0.0) return false;
+  double tt = -p.z / d.z;
+  if (tt <= RT_EPS) return false;
+  V3 P = p + (tt * d);
+  if (P.x < -0.5 || P.x > 0.5) return false;
+  if (P.y < -0.5 || P.y > 0.5) return false;
+  t = tt;
+  N = (d.z > 0.0) ? V3(0.0, 0.0, -1.0) : V3(0.0, 0.0, 1.0);
+  return true;
+}
+
+// Cylinder.cpp:28-93 (body), 95-150 (caps), 8-26 (combination); always capped (Cylinder.h:11)
+__device__ __forceinline__ bool cylinderBody(const V3& p, const V3& d, double& t, V3& N) {
+  double x0 = p.x, y0 = p.y, x1 = d.x, y1 = d.y;
+  double a = x1 * x1 + y1 * y1;
+  double b = 2.0 * (x0 * x1 + y0 * y1);
+  double c = x0 * x0 + y0 * y0 - 1.0;
+  if (0.0 == a) return false;
+  double disc = b * b - 4.0 * a * c;
+  if (disc < 0.0) return false;
+  disc = sqrt(disc);
+  double t2 = (-b + disc) / (2.0 * a);
+  if (t2 <= RT_EPS) return false;
+  double t1 = (-b - disc) / (2.0 * a);
+  if (t1 > RT_EPS) {
+    V3 P = p + (t1 * d);
+    if (P.z >= 0.0 && P.z <= 1.0) {
+      t = t1;
+      N = normalized(V3(P.x, P.y, 0.0));
+      return true;
+    }
+  }
+  V3 P = p + (t2 * d);
+  if (P.z >= 0.0 && P.z <= 1.0) {
+    t = t2;
+    N = normalized(V3(P.x, P.y, 0.0));
+    return true;
+  }
+  return false;
+}
+__device__ __forceinline__ bool cylinderCaps(const V3& p, const V3& d, double& t, V3& N) {
+  double pz = p.z, dz = d.z;
+  if (0.0 == dz) return false;
+  double t1, t2;
+  if (dz > 0.0) { t1 = (-pz) / dz; t2 = (1.0 - pz) / dz; }
+  else { t1 = (1.0 - pz) / dz; t2 = (-pz) / dz; }
+  if (t2 < RT_EPS) return false;
+  if (t1 >= RT_EPS) {
+    V3 q = p + (t1 * d);
+    if ((q.x * q.x + q.y * q.y) <= 1.0) {
+      t = t1;
+      N = (dz > 0.0) ? V3(0.0, 0.0, -1.0) : V3(0.0, 0.0, 1.0);
+      return true;
+    }
+  }
+  V3 q = p + (t2 * d);
+  if ((q.x * q.x + q.y * q.y) <= 1.0) {
+    t = t2;
+    N = (dz > 0.0) ? V3(0.0, 0.0, 1.0) : V3(0.0, 0.0, -1.0);
+    return true;
+  }
+  return false;
+}
+__device__ __forceinline__ bool cylinderLocal(const V3& p, const V3& d, double& t, V3& N) {
+  if (cylinderCaps(p, d, t, N)) {
+    double tb;
+    V3 Nb;
+    if (cylinderBody(p, d, tb, Nb)) {
+      if (tb < t) { t = tb; N = Nb; }
+    }
+    return true;
+  }
+  return cylinderBody(p, d, t, N);
+}
+
+// Cone.cpp:7-114
+__device__ __forceinline__ bool coneLocal(const RtObject& o, const V3& p, const V3& d, double& t, V3& N) {
+  const double beta_squared = o.cone_beta_squared, gamma = o.cone_gamma, height = o.cone_height;
+  const bool capped = o.capped != 0;
+  V3 normal;
+  double pz = p.z, dz = d.z;
+  double a = d.x * d.x + d.y * d.y - beta_squared * d.z * d.z;
+  if (a == 0.0) return false;
+  double b = 2 * (p.x * d.x + p.y * d.y - beta_squared * ((p.z + gamma) * d.z));
+  double c = -beta_squared * (gamma + p.z) * (gamma + p.z) + p.x * p.x + p.y * p.y;
+  double disc = b * b - 4 * a * c;
+  double theRoot = RT_EPS;
+  if (disc <= 0) return false;
+  disc = sqrt(disc);
+  double nearRoot = (-b + disc) / (2 * a);
+  double farRoot = (-b - disc) / (2 * a);
+  V3 qn = p + (nearRoot * d);
+  bool nearGood = !(qn.z < 0 || qn.z > height);
+  if (nearGood && (nearRoot > theRoot)) {
+    theRoot = nearRoot;
+    normal = V3(qn.x, qn.y, -2.0 * beta_squared * (qn.z + gamma));
+  }
+  V3 qf = p + (farRoot * d);
+  bool farGood = !(qf.z < 0 || qf.z > height);
+  if (farGood && ((nearGood && farRoot < theRoot) || farRoot > RT_EPS)) {
+    theRoot = farRoot;
+    normal = V3(qf.x, qf.y, -2.0 * beta_squared * (qf.z + gamma));
+  }
+  if (!capped && dot(normal, d) > 0) normal = -normal;
+  double t1 = (-pz) / dz;
+  double t2 = (height - pz) / dz;
+  if (capped) {
+    V3 q1 = p + (t1 * d);
+    if (q1.x * q1.x + q1.y * q1.y <= o.cone_b_radius * o.cone_b_radius) {
+      if (t1 < theRoot && t1 > RT_EPS) {
+        theRoot = t1;
+        normal = (dz > 0.0) ? V3(0.0, 0.0, -1.0) : V3(0.0, 0.0, 1.0);
+      }
+    }
+    V3 q2 = p + (t2 * d);
+    if (q2.x * q2.x + q2.y * q2.y <= o.cone_t_radius * o.cone_t_radius) {
+      if (t2 < theRoot && t2 > RT_EPS) {
+        theRoot = t2;
+        normal = (dz > 0.0) ? V3(0.0, 0.0, 1.0) : V3(0.0, 0.0, -1.0);
+      }
+    }
+  }
+  if (theRoot <= RT_EPS) return false;
+  t = theRoot;
+  N = normalized(normal);
+  return true;
+}
+
+// World ray -> object space, Geometry::intersect (scene.cpp:17-20)
+struct LocalRay { V3 p, d; double len; };
+__device__ __forceinline__ LocalRay toLocal(const double* inverse, const V3& p, const V3& d) {
+  LocalRay r;
+  r.p = xformPoint(inverse, p);
+  V3 dir = xformPoint(inverse, p + d) - r.p;
+  r.len = length(dir);
+  r.d = V3(dir.x / r.len, dir.y / r.len, dir.z / r.len);
+  return r;
+}
+
+// Geometry::intersect for a non-mesh object: world t and (optionally) world N.
+template <bool WANT_N>
+__device__ __forceinline__ bool objectIntersect(const RtObject& o, const V3& p, const V3& d,
+                                                double& t, V3& N) {
+  double tmin, tmax;
+  if (!boxIntersect(o.bbox_min, o.bbox_max, p, d, tmin, tmax)) return false;
+  LocalRay lr = toLocal(o.inverse, p, d);
+  double tl = 0.0;
+  V3 Nl;
+  bool hit = false;
+  switch (o.kind) {
+    case RT_OBJ_SPHERE: hit = sphereLocal(lr.p, lr.d, tl, Nl); break;
+    case RT_OBJ_BOX: hit = boxLocal(lr.p, lr.d, tl, Nl); break;
+    case RT_OBJ_SQUARE: hit = squareLocal(lr.p, lr.d, tl, Nl); break;
+    case RT_OBJ_CYLINDER: hit = cylinderLocal(lr.p, lr.d, tl, Nl); break;
+    case RT_OBJ_CONE: hit = coneLocal(o, lr.p, lr.d, tl, Nl); break;
+    default: break;
+  }
+  if (!hit) return false;
+  t = tl / lr.len;
+  if (WANT_N) N = normalized(mul33(o.normi, Nl));  // scene.h:168-172
+  return true;
+}
+
+// TrimeshFace::intersectLocal (trimesh.cpp:91-208), hit decision and local t.
+// sqrt(0 + 0 + z*z) of the reference's 3-D cross product of two vectors with
+// zero third component equals |z| exactly in binary64 (no over/underflow at
+// scene scales), so the four square roots are written as fabs.
+template <bool FAST>
+__device__ __forceinline__ bool triTest(const DevTri& T, const V3& lp, const V3& ld, bool cullBack,
+                                        double& rayT, V3* bary) {
+  const V3 n(T.n);
+  const double nd = dot(n, ld);
+  if (cullBack && nd > 0) return false;
+  if (nd == 0) return false;
+  rayT = -(dot(n, lp) + T.dconst) / nd;
+  if (rayT < RT_EPS) return false;
+  const V3 P = lp + rayT * ld;
+  const int ax = T.axes & 3, ay = (T.axes >> 2) & 3;
+  const double a0 = T.v0[ax], a1 = T.v0[ay], b0 = T.v1[ax], b1 = T.v1[ay];
+  const double c0 = T.v2[ax], c1 = T.v2[ay], p0 = P.get(ax), p1 = P.get(ay);
+  // z components of (b-p)x(c-p), (p-a)x(c-a), (b-a)x(p-a)  (trimesh.cpp:163-165)
+  const double pbc = fabs((b0 - p0) * (c1 - p1) - (b1 - p1) * (c0 - p0)) / 2;
+  const double apc = fabs((p0 - a0) * (c1 - a1) - (p1 - a1) * (c0 - a0)) / 2;
+  const double abp = fabs((b0 - a0) * (p1 - a1) - (b1 - a1) * (p0 - a0)) / 2;
+  if (FAST && bary == nullptr) {
+    const double s = pbc + apc + abp;
+    return s <= T.abc * (1 + RT_EPS) && s >= T.abc * (1 - RT_EPS);
+  }
+  const double w0 = pbc / T.abc, w1 = apc / T.abc, w2 = abp / T.abc;
+  const double total = w0 + w1 + w2;
+  if (bary) *bary = V3(w0, w1, w2);
+  return total <= (1 + RT_EPS) && total >= (1 - RT_EPS);
+}
+
+// Local bounding box of a face = componentwise extrema of its vertices
+// (TrimeshFace::ComputeLocalBoundingBox, trimesh.h:136-145)
+__device__ __forceinline__ bool faceBoxCull(const DevTri& T, const V3& p, const V3& d) {
+  double lo[3], hi[3];
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    hi[a] = fmax(T.v2[a], fmax(T.v0[a], T.v1[a]));
+    lo[a] = fmin(T.v2[a], fmin(T.v0[a], T.v1[a]));
+  }
+  double t0, t1;
+  return boxIntersect(lo, hi, p, d, t0, t1);
+}
+
+// ------------------------------------------------------------------- traversal
+#define RT_STACK_DEPTH 96
+#define RT_ENTRY_RESUME 0x80000000u
+
+template <bool FAST> struct StackEntry;
+template <> struct StackEntry<false> { uint32_t node; double tmin, tmax; };
+template <> struct StackEntry<true> { uint32_t node; float tmin, tmax; };
+
+__device__ __forceinline__ float roundDown(double x) {
+  float f = (float)x;
+  return ((double)f > x) ? nextafterf(f, -INFINITY) : f;
+}
+__device__ __forceinline__ float roundUp(double x) {
+  float f = (float)x;
+  return ((double)f < x) ? nextafterf(f, INFINITY) : f;
+}
+
+// Scene::intersect.  Returns the winning primitive (RT_PRIM_NONE on a miss)
+// and its world-space t.  `tLimit` (FAST only) bounds the search: hits beyond
+// it are of no interest to the caller (shadow rays towards a positional light).
+template <bool FAST, bool STATS>
+__device__ int traceClosest(const DevScene& S, const V3& p, const V3& d, int rayType, double tLimit,
+                            double& tOut, TraceCounters& cnt) {
+  bool haveOne = false;
+  double bestT = 0.0;
+  int bestPrim = RT_PRIM_NONE;
+  const bool cullBack = S.cull && rayType != RT_RAY_REFRACTION;
+
+  if (!(S.use_kd && S.scene_root >= 0)) {
+    // Linear scan of Scene::objects (scene.cpp:144-153); meshes through
+    // Trimesh::intersectLocal (trimesh.cpp:62-82): no per-face box cull.
+    for (int j = 0; j < S.n_objects; j++) {
+      const RtObject& o = S.objects[j];
+      if (o.kind == RT_OBJ_TRIMESH) {
+        double tmin, tmax;
+        if (!boxIntersect(o.bbox_min, o.bbox_max, p, d, tmin, tmax)) continue;
+        const LocalRay lr = toLocal(o.inverse, p, d);
+        const RtMesh& m = S.meshes[o.mesh];
+        bool meshHave = false;
+        double meshT = 0.0;
+        int meshFace = -1;
+        for (int k = 0; k < m.n_faces; k++) {
+          const DevTri& T = S.tris[m.first_face + k];
+          double rt;
+          V3 bary;
+          if (STATS) cnt.prims++;
+          if (triTest<false>(T, lr.p, lr.d, cullBack, rt, &bary)) {
+            if (!meshHave || rt < meshT) { meshHave = true; meshT = rt; meshFace = m.first_face + k; }
+          }
+        }
+        if (meshHave) {
+          double tw = meshT / lr.len;
+          if (!haveOne || tw < bestT) { haveOne = true; bestT = tw; bestPrim = RT_PRIM_FACE | meshFace; }
+        }
+      } else {
+        double t;
+        V3 N;
+        if (STATS) cnt.prims++;
+        if (objectIntersect<false>(o, p, d, t, N)) {
+          if (!haveOne || t < bestT) { haveOne = true; bestT = t; bestPrim = j; }
+        }
+      }
+    }
+    tOut = bestT;
+    return bestPrim;
+  }
+
+  StackEntry<FAST> stack[RT_STACK_DEPTH];
+  int sp = 0;
+  // function-level interval of the reference's current intersectKdTree call
+  double fMin = 0.0, fMax = 0.0, sceneFMin, sceneFMax;
+  {
+    bool hitBox = boxIntersect(S.scene_bb_min, S.scene_bb_max, p, d, fMin, fMax);
+    if (FAST) {
+      if (!hitBox) { tOut = 0.0; return RT_PRIM_NONE; }
+      if (fMin < 0.0) fMin = 0.0;
+      if (fMax > tLimit) fMax = tLimit;
+      stack[sp].tmin = roundDown(fMin);
+      stack[sp].tmax = roundUp(fMax);
+    } else {
+      stack[sp].tmin = fMin;
+      stack[sp].tmax = fMax;
+    }
+    stack[sp].node = (uint32_t)S.scene_root;
+    sp++;
+  }
+  sceneFMin = fMin;
+  sceneFMax = fMax;
+  bool inMesh = false;
+  int meshOwner = -1;
+  LocalRay lr;
+  lr.len = 1.0;
+
+  while (sp > 0) {
+    --sp;
+    uint32_t nidx = stack[sp].node;
+    int k0 = 0;
+    if (nidx & RT_ENTRY_RESUME) {
+      // back in the scene-level leaf loop after a nested mesh traversal
+      nidx &= ~RT_ENTRY_RESUME;
+      k0 = FAST ? (int)stack[sp].tmin : (int)stack[sp].tmin;
+      inMesh = false;
+      fMin = sceneFMin;
+      fMax = sceneFMax;
+    } else if (FAST) {
+      if (haveOne && (double)stack[sp].tmin > bestT) continue;
+    }
+    const double eMin = (double)stack[sp].tmin, eMax = (double)stack[sp].tmax;
+    const DevNode nd = S.nodes[nidx];
+    if (STATS) cnt.nodes++;
+    if ((nd.a & 3u) == 3u) {
+      const int first = (int)(nd.a >> 2), count = (int)nd.b;
+      if (!inMesh) {
+        for (int k = k0; k < count; k++) {
+          const int oi = S.items[first + k];
+          const RtObject& o = S.objects[oi];
+          if (o.kind == RT_OBJ_TRIMESH) {
+            const RtMesh& m = S.meshes[o.mesh];
+            double a0 = 0.0, a1 = 0.0;
+            bool hitBox = boxIntersect(m.root_bb_min, m.root_bb_max, p, d, a0, a1);
+            if (m.kd_root < 0) continue;
+            if (FAST) {
+              if (!hitBox) continue;
+              if (a0 < 0.0) a0 = 0.0;
+              if (a1 > tLimit) a1 = tLimit;
+              if (haveOne && a0 > bestT) continue;
+            }
+            if (sp + 2 > RT_STACK_DEPTH) continue;
+            stack[sp].node = nidx | RT_ENTRY_RESUME;
+            stack[sp].tmin = (k + 1);
+            stack[sp].tmax = 0;
+            sp++;
+            stack[sp].node = (uint32_t)m.kd_root;
+            if (FAST) { stack[sp].tmin = roundDown(a0); stack[sp].tmax = roundUp(a1); }
+            else { stack[sp].tmin = a0; stack[sp].tmax = a1; }
+            sp++;
+            inMesh = true;
+            meshOwner = oi;
+            fMin = a0;
+            fMax = a1;
+            lr = toLocal(o.inverse, p, d);
+            break;
+          }
+          double t;
+          V3 N;
+          if (STATS) cnt.prims++;
+          if (objectIntersect<false>(o, p, d, t, N)) {
+            if (!haveOne || t < bestT) { haveOne = true; bestT = t; bestPrim = oi; }
+          }
+        }
+      } else {
+        for (int k = 0; k < count; k++) {
+          const int fi = S.items[first + k];
+          const DevTri& T = S.tris[fi];
+          if (STATS) cnt.prims++;
+          if (!FAST) {
+            if (!faceBoxCull(T, p, d)) continue;
+          }
+          double rt;
+          if (triTest<FAST>(T, lr.p, lr.d, cullBack, rt, nullptr)) {
+            double tw = rt / lr.len;
+            if (!haveOne || tw < bestT) { haveOne = true; bestT = tw; bestPrim = RT_PRIM_FACE | fi; }
+          }
+        }
+      }
+    } else {
+      const int dim = (int)(nd.a & 3u);
+      const uint32_t left = nd.a >> 2, right = nd.b;
+      const double po = p.get(dim), di = d.get(dim);
+      const double tStar = (nd.split - po) / di;
+      if (!FAST) {
+        // scene.cpp:96-124: pushed intervals come from the function-level
+        // tMin/tMax, not from the popped element
+        uint32_t nearN, farN;
+        if (po < nd.split) { nearN = left; farN = right; } else { nearN = right; farN = left; }
+        if (sp + 2 > RT_STACK_DEPTH) continue;
+        if (tStar > eMax || tStar < 0) {
+          stack[sp].node = nearN; stack[sp].tmin = fMin; stack[sp].tmax = fMax; sp++;
+        } else if (tStar < eMin) {
+          stack[sp].node = farN; stack[sp].tmin = fMin; stack[sp].tmax = fMax; sp++;
+        } else if (eMin <= tStar && tStar <= eMax) {
+          stack[sp].node = nearN; stack[sp].tmin = fMin; stack[sp].tmax = tStar; sp++;
+          stack[sp].node = farN; stack[sp].tmin = tStar; stack[sp].tmax = fMax; sp++;
+        }
+      } else {
+        // near side by origin; an origin exactly on the plane belongs to the
+        // side the ray moves into
+        const bool leftNear = (po < nd.split) || (po == nd.split && di < 0);
+        const uint32_t nearN = leftNear ? left : right, farN = leftNear ? right : left;
+        if (sp + 2 > RT_STACK_DEPTH) continue;
+        if (tStar != tStar) {  // ray inside the split plane: both sides, same interval
+          stack[sp].node = farN; stack[sp].tmin = (float)eMin; stack[sp].tmax = (float)eMax; sp++;
+          stack[sp].node = nearN; stack[sp].tmin = (float)eMin; stack[sp].tmax = (float)eMax; sp++;
+        } else if (tStar > eMax || tStar <= 0) {
+          stack[sp].node = nearN; stack[sp].tmin = (float)eMin; stack[sp].tmax = (float)eMax; sp++;
+        } else if (tStar < eMin) {
+          stack[sp].node = farN; stack[sp].tmin = (float)eMin; stack[sp].tmax = (float)eMax; sp++;
+        } else {
+          stack[sp].node = farN; stack[sp].tmin = roundDown(tStar); stack[sp].tmax = (float)eMax; sp++;
+          stack[sp].node = nearN; stack[sp].tmin = (float)eMin; stack[sp].tmax = roundUp(tStar); sp++;
+        }
+      }
+    }
+  }
+  (void)meshOwner;
+  tOut = bestT;
+  return bestPrim;
+}
+
+}  // namespace rtd

@@ -1,0 +1,111 @@
+"""Python face of the HIP render path (raytracer_amd/csrc/rt_kernels.hip built
+as librt_amd.so).  Everything goes through the C-ABI of include/rt_amd.h.
+There is no CPU fallback: a missing library or a failing HIP call raises."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class DeviceError(RuntimeError):
+    pass
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "librt_amd.so")
+        if not os.path.exists(path):
+            raise DeviceError("librt_amd.so (the HIP extension) is not built; "
+                              "run `python -c 'import __graft_entry__ as g; g.build()'`")
+        _LIB = abi.bind(C.CDLL(path), abi.RT_AMD_SYMBOLS)
+        if _LIB.rt_abi_version() != abi.RT_AMD_ABI_VERSION:
+            raise DeviceError("librt_amd.so ABI version mismatch")
+    return _LIB
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise DeviceError("%s failed (%d): %s" % (what, rc, lib().rt_last_error().decode()))
+
+
+class DeviceScene:
+    """RtScene handle: the flattened scene resident in HBM on the current HIP device."""
+
+    def __init__(self, desc_ptr):
+        self._h = C.c_void_p()
+        _check(lib().rt_scene_create(desc_ptr, C.byref(self._h)), "rt_scene_create")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().rt_scene_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def render(self, params, want_hits=True):
+        """Host-output render: returns (rgb[h,w,3] uint8 with row 0 = bottom row,
+        primary-hit objectIDs [h,w] int32 or None, RtStats)."""
+        assert not params.out_is_device
+        h, w = params.height, params.width
+        rgb = np.zeros((h, w, 3), dtype=np.uint8)
+        hits = np.zeros((h, w), dtype=np.int32) if want_hits else None
+        st = abi.RtStats()
+        _check(lib().rt_render(self._h, C.byref(params), rgb.ctypes.data,
+                               hits.ctypes.data if want_hits else None, C.byref(st)), "rt_render")
+        return rgb, hits, st
+
+    def render_into(self, params, rgb, hits=None):
+        """Host-output render into caller arrays (only this shard's pixels are written)."""
+        assert not params.out_is_device
+        st = abi.RtStats()
+        _check(lib().rt_render(self._h, C.byref(params), rgb.ctypes.data,
+                               hits.ctypes.data if hits is not None else None, C.byref(st)), "rt_render")
+        return st
+
+    def render_device(self, params, rgb_dev_ptr, hit_dev_ptr=None):
+        """Device-output render: packed tile buffer(s) of this shard at the given
+        device addresses (e.g. torch tensor .data_ptr())."""
+        assert params.out_is_device
+        st = abi.RtStats()
+        _check(lib().rt_render(self._h, C.byref(params), C.c_void_p(rgb_dev_ptr),
+                               C.c_void_p(hit_dev_ptr) if hit_dev_ptr else None, C.byref(st)), "rt_render")
+        return st
+
+    def intersect(self, rays_pd, types=None, traversal=abi.RT_TRAVERSE_REFERENCE):
+        rays = np.ascontiguousarray(rays_pd, dtype=np.float64).reshape(-1, 6)
+        n = len(rays)
+        ty = np.ascontiguousarray(types, dtype=np.int32) if types is not None else None
+        hits = (abi.RtHit * n)()
+        _check(lib().rt_intersect_batch(self._h, traversal, n, rays.ctypes.data_as(abi.PD),
+                                        ty.ctypes.data_as(abi.PI) if ty is not None else None, hits),
+               "rt_intersect_batch")
+        return hits
+
+
+def shard_pixels(width, height, tile_w, tile_h, shard_index, shard_count):
+    return lib().rt_shard_pixels(width, height, tile_w, tile_h, shard_index, shard_count)
+
+
+def unpack_tiles(packed_ptr, bytes_per_pixel, width, height, tile_w, tile_h, shard_index, shard_count,
+                 frame_ptr, stream=0):
+    _check(lib().rt_unpack_tiles(C.c_void_p(packed_ptr), bytes_per_pixel, width, height, tile_w, tile_h,
+                                 shard_index, shard_count, C.c_void_p(frame_ptr), C.c_void_p(stream)),
+           "rt_unpack_tiles")
+
+
+def edge_mask(rgb, cutoff):
+    rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+    h, w = rgb.shape[:2]
+    out = np.zeros((h, w), dtype=np.uint8)
+    _check(lib().rt_edge_mask(rgb.ctypes.data, w, h, cutoff, out.ctypes.data), "rt_edge_mask")
+    return out

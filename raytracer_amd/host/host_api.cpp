@@ -135,4 +135,23 @@ int rth_read_bmp(const char* path, int w, int h, unsigned char* rgb) {
   return 0;
 }
 
+// sizeof of each C-ABI struct, so that foreign-language bindings can verify
+// their mirrored layouts: 0 RtLight, 1 RtMaterial, 2 RtObject, 3 RtMesh, 4 RtFace,
+// 5 RtSceneDesc, 6 RtRenderParams, 7 RtStats, 8 RtHit, 9 RthOptions.
+int rth_abi_sizeof(int which) {
+  switch (which) {
+    case 0: return (int)sizeof(RtLight);
+    case 1: return (int)sizeof(RtMaterial);
+    case 2: return (int)sizeof(RtObject);
+    case 3: return (int)sizeof(RtMesh);
+    case 4: return (int)sizeof(RtFace);
+    case 5: return (int)sizeof(RtSceneDesc);
+    case 6: return (int)sizeof(RtRenderParams);
+    case 7: return (int)sizeof(RtStats);
+    case 8: return (int)sizeof(RtHit);
+    case 9: return (int)sizeof(RthOptions);
+  }
+  return -1;
+}
+
 }  // extern "C"

@@ -35,6 +35,7 @@ int rth_jitter_table(unsigned seed, int n, double* out);
 int rth_write_bmp(const char* path, int w, int h, const unsigned char* rgb);
 int rth_read_bmp_size(const char* path, int* w, int* h);
 int rth_read_bmp(const char* path, int w, int h, unsigned char* rgb);
+int rth_abi_sizeof(int which);
 
 #ifdef __cplusplus
 }

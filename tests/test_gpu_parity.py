@@ -1,0 +1,246 @@
+"""GPU parity tests: the HIP path (through the C-ABI) against the CPU oracle on
+the same flattened scene and the same seeded inputs."""
+import numpy as np
+import pytest
+
+from raytracer_amd import abi, device, host, scenes
+from oracle import loader
+from tests import common
+
+pytestmark = pytest.mark.gpu
+
+BOTH = [abi.RT_TRAVERSE_REFERENCE, abi.RT_TRAVERSE_FAST]
+
+
+def _render_both(hs, **kw):
+    ds = device.DeviceScene(hs.desc_ptr)
+    p, keep = host.render_params(**kw)
+    rgb, hits, st = ds.render(p)
+    ref_rgb, ref_hits, ref_st = loader.render(hs.desc_ptr, p, threads=8)
+    ds.close()
+    return rgb, hits, st, ref_rgb, ref_hits, ref_st
+
+
+def _ray_counts(st):
+    return (st.rays_primary, st.rays_reflect, st.rays_refract, st.rays_shadow)
+
+
+@pytest.mark.parametrize("trav", BOTH)
+def test_simple_scene(built, trav):
+    hs = host.HostScene(text=scenes.simple_scene())
+    rgb, hits, st, rr, rh, rs = _render_both(hs, width=128, height=128, depth=2, traversal=trav)
+    common.assert_parity(rgb, hits, rr, rh, what="simple")
+    assert _ray_counts(st) == _ray_counts(rs)
+    assert st.shade_points == rs.shade_points
+
+
+@pytest.mark.parametrize("trav", BOTH)
+def test_simple_scene_non_square_and_odd_size(built, trav):
+    hs = host.HostScene(text=scenes.simple_scene())
+    rgb, hits, st, rr, rh, rs = _render_both(hs, width=101, height=67, depth=3, traversal=trav)
+    common.assert_parity(rgb, hits, rr, rh, what="simple 101x67")
+    assert _ray_counts(st) == _ray_counts(rs)
+
+
+@pytest.mark.parametrize("trav", BOTH)
+def test_depth_zero_and_deep(built, trav):
+    hs = host.HostScene(text=scenes.simple_scene())
+    for depth in (0, 6):
+        rgb, hits, st, rr, rh, rs = _render_both(hs, width=64, height=64, depth=depth, traversal=trav)
+        common.assert_parity(rgb, hits, rr, rh, what="depth %d" % depth)
+        assert _ray_counts(st) == _ray_counts(rs)
+
+
+@pytest.mark.parametrize("trav", BOTH)
+def test_mesh_scene(built, trav):
+    hs = host.HostScene(text=common.small_mesh_scene(3))
+    rgb, hits, st, rr, rh, rs = _render_both(hs, width=160, height=90, depth=3, traversal=trav)
+    common.assert_parity(rgb, hits, rr, rh, what="mesh")
+    assert _ray_counts(st) == _ray_counts(rs)
+
+
+@pytest.mark.parametrize("trav", BOTH)
+def test_heightfield_scene(built, trav):
+    hs = host.HostScene(text=common.small_heightfield_scene(24), kd_max_depth=22)
+    rgb, hits, st, rr, rh, rs = _render_both(hs, width=128, height=72, depth=5, traversal=trav)
+    common.assert_parity(rgb, hits, rr, rh, what="heightfield")
+    assert _ray_counts(st) == _ray_counts(rs)
+
+
+@pytest.mark.parametrize("trav", BOTH)
+def test_all_primitives(built, trav):
+    hs = host.HostScene(text=common.all_primitives_scene())
+    rgb, hits, st, rr, rh, rs = _render_both(hs, width=160, height=120, depth=3, traversal=trav)
+    common.assert_parity(rgb, hits, rr, rh, what="primitives")
+    assert _ray_counts(st) == _ray_counts(rs)
+
+
+@pytest.mark.parametrize("trav", BOTH)
+def test_vertex_materials(built, trav):
+    hs = host.HostScene(text=common.vertex_material_scene())
+    rgb, hits, st, rr, rh, rs = _render_both(hs, width=96, height=96, depth=3, traversal=trav)
+    common.assert_parity(rgb, hits, rr, rh, what="vertex materials")
+    assert _ray_counts(st) == _ray_counts(rs)
+
+
+def test_options_off(built):
+    """back-face culling off, smooth shading off, kd-tree off (linear scan)."""
+    for opts in (dict(backface_culling=False), dict(smooth_shading=False), dict(kd_tree=False)):
+        hs = host.HostScene(text=common.small_mesh_scene(2), **opts)
+        rgb, hits, st, rr, rh, rs = _render_both(hs, width=96, height=54, depth=2)
+        common.assert_parity(rgb, hits, rr, rh, what=str(opts))
+        assert _ray_counts(st) == _ray_counts(rs)
+
+
+@pytest.mark.parametrize("trav", BOTH)
+def test_cornell_cubemap_antialias(built, trav):
+    hs = host.HostScene(text=scenes.cornell_scene())
+    hs.set_cubemap(scenes.cube_map_faces(64, seed=3))
+    jit = host.jitter_table(1234567, 3)
+    rgb, hits, st, rr, rh, rs = _render_both(hs, width=96, height=54, depth=5, aa_mode=abi.RT_AA_FULL,
+                                             aa_samples=3, jitter=jit, use_cubemap=True, traversal=trav)
+    common.assert_parity(rgb, hits, rr, rh, what="cornell")
+    assert _ray_counts(st) == _ray_counts(rs)
+
+
+def test_cubemap_filter_widths(built):
+    hs = host.HostScene(text=scenes.cornell_scene())
+    hs.set_cubemap(scenes.cube_map_faces(32, seed=5))
+    for fw in (1, 2, 3, 6):
+        rgb, hits, st, rr, rh, rs = _render_both(hs, width=80, height=45, depth=2, use_cubemap=True,
+                                                 filter_width=fw)
+        common.assert_parity(rgb, hits, rr, rh, what="filter width %d" % fw)
+
+
+def test_total_internal_reflection_nan_pixels(built):
+    """A refraction ray past the critical angle has a NaN direction; with a cube
+    map the NaN reaches the pixel and both sides must write bytes (0,0,0)."""
+    s = scenes.HEADER
+    s += scenes.camera((0.0371, 0.0137, -4.0213), (0.0, 0.0, 1.0), aspect=1.0, fov=35.0)
+    s += scenes.ambient_light((0.3, 0.3, 0.3))
+    s += scenes.point_light((2.1237, 3.3411, -4.2173))
+    s += scenes.prim("sphere", scenes.material(diffuse=(0.1, 0.1, 0.1), ambient=(0.1, 0.1, 0.1),
+                                               transmissive=(0.9, 0.9, 0.9), index=1.5))
+    hs = host.HostScene(text=s)
+    hs.set_cubemap(scenes.cube_map_faces(32, seed=7))
+    rgb, hits, st, rr, rh, rs = _render_both(hs, width=100, height=100, depth=5, use_cubemap=True)
+    common.assert_parity(rgb, hits, rr, rh, what="TIR")
+    inside = rh > 0
+    assert ((rr[inside].sum(axis=1) == 0).sum()) > 0, "scene should produce NaN pixels"
+
+
+def test_adaptive_antialiasing(built):
+    hs = host.HostScene(text=scenes.simple_scene())
+    jit = host.jitter_table(99, 3)
+    rgb, hits, st, rr, rh, rs = _render_both(hs, width=120, height=120, depth=2,
+                                             aa_mode=abi.RT_AA_ADAPTIVE, aa_samples=3, aa_threshold=40,
+                                             jitter=jit)
+    common.assert_parity(rgb, hits, rr, rh, what="adaptive AA")
+    assert st.rays_primary == rs.rays_primary > 120 * 120
+
+
+def test_intersect_batch_bit_exact(built):
+    rng = np.random.RandomState(11)
+    for text, opts in ((common.small_mesh_scene(3), {}), (common.all_primitives_scene(), {}),
+                       (common.small_mesh_scene(2), dict(kd_tree=False))):
+        hs = host.HostScene(text=text, **opts)
+        ds = device.DeviceScene(hs.desc_ptr)
+        n = 4000
+        p = rng.uniform(-6, 6, size=(n, 3)) + np.array([0, 4, 0])
+        tgt = rng.uniform(-2.5, 2.5, size=(n, 3)) + np.array([0, 1.0, 0])
+        d = tgt - p
+        d /= np.linalg.norm(d, axis=1)[:, None]
+        rays = np.concatenate([p, d], axis=1)
+        types = rng.choice([abi.RT_RAY_VISIBILITY, abi.RT_RAY_REFLECTION, abi.RT_RAY_REFRACTION,
+                            abi.RT_RAY_SHADOW], size=n).astype(np.int32)
+        ref = loader.intersect_batch(hs.desc_ptr, rays, types)
+        for trav in BOTH:
+            got = ds.intersect(rays, types, trav)
+            for k in range(n):
+                assert got[k].object_id == ref[k].object_id, (k, trav)
+                assert got[k].t == ref[k].t, (k, trav)
+                assert list(got[k].N) == list(ref[k].N), (k, trav)
+                assert list(got[k].bary) == list(ref[k].bary), (k, trav)
+        ds.close()
+
+
+def test_sharded_tiles_assemble_to_single_device_frame(built):
+    """Interleaved tile shards rendered one after the other on one GPU must
+    assemble byte-identically into the single-shard frame (host and packed paths)."""
+    import torch
+    hs = host.HostScene(text=common.small_mesh_scene(2))
+    ds = device.DeviceScene(hs.desc_ptr)
+    w, h = 150, 84
+    p, _ = host.render_params(w, h, depth=2, tile_w=32, tile_h=16)
+    full, full_hits, _ = ds.render(p)
+    for shards in (2, 3, 8):
+        frame = np.zeros((h, w, 3), dtype=np.uint8)
+        hits = np.zeros((h, w), dtype=np.int32)
+        dev_frame = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda")
+        total_px = 0
+        for s in range(shards):
+            ps, _ = host.render_params(w, h, depth=2, tile_w=32, tile_h=16, shard_index=s, shard_count=shards)
+            ds.render_into(ps, frame, hits)
+            npx = device.shard_pixels(w, h, 32, 16, s, shards)
+            total_px += npx
+            pd, _ = host.render_params(w, h, depth=2, tile_w=32, tile_h=16, shard_index=s,
+                                       shard_count=shards, out_is_device=True)
+            packed = torch.zeros((max(npx, 1), 3), dtype=torch.uint8, device="cuda")
+            ds.render_device(pd, packed.data_ptr())
+            torch.cuda.synchronize()
+            device.unpack_tiles(packed.data_ptr(), 3, w, h, 32, 16, s, shards, dev_frame.data_ptr(),
+                                torch.cuda.current_stream().cuda_stream)
+        assert total_px == w * h
+        assert np.array_equal(frame, full) and np.array_equal(hits, full_hits)
+        assert np.array_equal(dev_frame.cpu().numpy(), full)
+    ds.close()
+
+
+def test_small_batches_and_pool_overflow_split(built):
+    """Forcing tiny batches (and therefore pool overflow + batch splitting)
+    must not change a single byte."""
+    hs = host.HostScene(text=scenes.simple_scene())
+    ds = device.DeviceScene(hs.desc_ptr)
+    p, _ = host.render_params(96, 96, depth=4)
+    a, ah, sa = ds.render(p)
+    p2, _ = host.render_params(96, 96, depth=4, max_batch_samples=2048)
+    b, bh, sb = ds.render(p2)
+    assert np.array_equal(a, b) and np.array_equal(ah, bh)
+    assert sb.batches > sa.batches
+    assert (sa.rays_primary, sa.rays_reflect, sa.rays_refract, sa.rays_shadow) == \
+           (sb.rays_primary, sb.rays_reflect, sb.rays_refract, sb.rays_shadow)
+    ds.close()
+
+
+def test_stats_counters(built):
+    hs = host.HostScene(text=common.small_mesh_scene(3))
+    ds = device.DeviceScene(hs.desc_ptr)
+    for trav in BOTH:
+        p, _ = host.render_params(96, 54, depth=2, traversal=trav, collect_stats=True)
+        rgb, hits, st = ds.render(p)
+        assert st.nodes_visited > st.rays_total and st.prims_tested > 0
+        assert st.ms_trace > 0 and st.ms_device >= st.ms_trace and st.trace_launches >= 2
+    ds.close()
+
+
+def test_edge_mask_matches_oracle(built):
+    rng = np.random.RandomState(3)
+    img = (rng.uniform(size=(37, 53, 3)) * 255).astype(np.uint8)
+    img[10:20, 10:30] = 250
+    for cutoff in (20, 180):
+        assert np.array_equal(device.edge_mask(img, cutoff), loader.edge_mask(img, cutoff))
+
+
+def test_error_paths(built):
+    hs = host.HostScene(text=scenes.simple_scene())
+    ds = device.DeviceScene(hs.desc_ptr)
+    p, _ = host.render_params(64, 64, tile_w=12, tile_h=8)
+    with pytest.raises(device.DeviceError):
+        ds.render(p)
+    p, _ = host.render_params(0, 64)
+    with pytest.raises(device.DeviceError):
+        ds.render(p)
+    bad = abi.RtSceneDesc()
+    with pytest.raises(device.DeviceError):
+        device.DeviceScene(bad)
+    ds.close()
