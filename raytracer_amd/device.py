@@ -20,6 +20,14 @@ def lib():
     global _LIB
     if _LIB is None:
         path = os.path.join(_HERE, "librt_amd.so")
+        # PyTorch-ROCm ships its own libamdhip64.so.7 / libhsa-runtime64; two HIP
+        # runtimes in one process cannot both own the GPU.  Loading torch's first
+        # makes this library (NEEDED libamdhip64.so.7) bind to the same runtime,
+        # so torch tensors and RCCL buffers can be handed to rt_render.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         if not os.path.exists(path):
             raise DeviceError("librt_amd.so (the HIP extension) is not built; "
                               "run `python -c 'import __graft_entry__ as g; g.build()'`")

@@ -67,12 +67,26 @@ def test_heightfield_scene(built, trav):
     assert _ray_counts(st) == _ray_counts(rs)
 
 
-@pytest.mark.parametrize("trav", BOTH)
-def test_all_primitives(built, trav):
-    hs = host.HostScene(text=common.all_primitives_scene())
-    rgb, hits, st, rr, rh, rs = _render_both(hs, width=160, height=120, depth=3, traversal=trav)
-    common.assert_parity(rgb, hits, rr, rh, what="primitives")
+def test_all_primitives(built):
+    """Secondary rays start on the axis-aligned floor square, whose plane is a
+    KD split plane; there the reference's traversal (far child only when the
+    origin sits on the plane) loses hits that a true closest-hit query finds.
+    REFERENCE traversal must reproduce the reference's KD result; FAST is a
+    true closest-hit query and must equal the reference's own linear scan."""
+    text = common.all_primitives_scene()
+    hs = host.HostScene(text=text)
+    rgb, hits, st, rr, rh, rs = _render_both(hs, width=160, height=120, depth=3,
+                                             traversal=abi.RT_TRAVERSE_REFERENCE)
+    common.assert_parity(rgb, hits, rr, rh, what="primitives, reference traversal")
     assert _ray_counts(st) == _ray_counts(rs)
+    ds = device.DeviceScene(hs.desc_ptr)
+    p, _ = host.render_params(160, 120, depth=3, traversal=abi.RT_TRAVERSE_FAST)
+    frgb, fhits, fst = ds.render(p)
+    ds.close()
+    lin = host.HostScene(text=text, kd_tree=False)
+    lrgb, lhits, lst = loader.render(lin.desc_ptr, p, threads=8)
+    common.assert_parity(frgb, fhits, lrgb, lhits, what="primitives, fast traversal vs linear scan")
+    assert _ray_counts(fst) == _ray_counts(lst)
 
 
 @pytest.mark.parametrize("trav", BOTH)
@@ -116,17 +130,18 @@ def test_total_internal_reflection_nan_pixels(built):
     """A refraction ray past the critical angle has a NaN direction; with a cube
     map the NaN reaches the pixel and both sides must write bytes (0,0,0)."""
     s = scenes.HEADER
-    s += scenes.camera((0.0371, 0.0137, -4.0213), (0.0, 0.0, 1.0), aspect=1.0, fov=35.0)
+    s += scenes.camera((0.0371, 1.5137, -4.0213), (0.0, -0.35, 1.0), aspect=1.0, fov=35.0)
     s += scenes.ambient_light((0.3, 0.3, 0.3))
     s += scenes.point_light((2.1237, 3.3411, -4.2173))
-    s += scenes.prim("sphere", scenes.material(diffuse=(0.1, 0.1, 0.1), ambient=(0.1, 0.1, 0.1),
-                                               transmissive=(0.9, 0.9, 0.9), index=1.5))
+    glass = scenes.material(diffuse=(0.1, 0.1, 0.1), ambient=(0.1, 0.1, 0.1),
+                            transmissive=(0.9, 0.9, 0.9), index=1.5)
+    s += scenes.rotate((0.0, 1.0, 0.0), 0.5, scenes.scale((1.6, 1.6, 1.6), scenes.prim("box", glass)))
     hs = host.HostScene(text=s)
     hs.set_cubemap(scenes.cube_map_faces(32, seed=7))
     rgb, hits, st, rr, rh, rs = _render_both(hs, width=100, height=100, depth=5, use_cubemap=True)
     common.assert_parity(rgb, hits, rr, rh, what="TIR")
     inside = rh > 0
-    assert ((rr[inside].sum(axis=1) == 0).sum()) > 0, "scene should produce NaN pixels"
+    assert ((rr[inside].sum(axis=1) == 0).sum()) > 1000, "scene should produce NaN pixels"
 
 
 def test_adaptive_antialiasing(built):
