@@ -35,6 +35,7 @@
 #include <vector>
 
 #include "../../include/rt_amd.h"
+#include "rt_bvh.h"
 #include "rt_shade.h"
 
 using namespace rtd;
@@ -162,7 +163,8 @@ k_trace(DevScene S, int n, const double* rayP, const double* rayD, const int* ra
     double t = 0.0;
     if (type >= 0) {
       const V3 p = loadV3(rayP, stride, i), d = loadV3(rayD, stride, i);
-      prim = traceClosest<FAST, STATS>(S, p, d, type, 1.0e308, t, tc);
+      if (FAST) prim = traceBvh<false, STATS>(S, p, d, type, 1.0e308, -1.0, t, tc);
+      else prim = traceKdReference<STATS>(S, p, d, type, t, tc);
     }
     hitT[i] = t;
     hitPrim[i] = prim;
@@ -255,7 +257,13 @@ k_lights(DevScene S, long long nMax, Pool P) {
         const V3 sd = normalized(-V3(l.orientation));
         L = sd;
         double th;
-        const int prim = traceClosest<FAST, STATS>(S, Q, sd, RT_RAY_SHADOW, 1.0e308, th, tc);
+        int prim;
+        if (FAST) {
+          // any hit blacks a directional light out (light.cpp:21-24)
+          prim = traceBvh<true, STATS>(S, Q, sd, RT_RAY_SHADOW, 1.0e308, -1.0, th, tc);
+        } else {
+          prim = traceKdReference<STATS>(S, Q, sd, RT_RAY_SHADOW, th, tc);
+        }
         atten = (prim != RT_PRIM_NONE) ? V3(0, 0, 0) : color;
       } else {
         const V3 position(l.position);
@@ -265,10 +273,21 @@ k_lights(DevScene S, long long nMax, Pool P) {
         double th;
         // FAST: an occluder beyond the light is irrelevant; bound the search a
         // little past the light so that the strict < below decides
-        const double limit = FAST ? sqrt(lightDistance) * 1.0000001 + 1e-7 : 1.0e308;
-        const int prim = traceClosest<FAST, STATS>(S, Q, sd, RT_RAY_SHADOW, limit, th, tc);
+        const double limit = sqrt(lightDistance) * 1.0000001 + 1e-7;
+        int prim;
         bool occluded = false;
         V3 kt;
+        if (FAST && S.opaque) {
+          // Every material has kt == 0, so the filter colour of ANY occluder in
+          // front of the light is the closest occluder's: stop at the first one.
+          prim = traceBvh<true, STATS>(S, Q, sd, RT_RAY_SHADOW, limit, lightDistance, th, tc);
+          occluded = prim != RT_PRIM_NONE;
+          prim = RT_PRIM_NONE;
+        } else if (FAST) {
+          prim = traceBvh<false, STATS>(S, Q, sd, RT_RAY_SHADOW, limit, -1.0, th, tc);
+        } else {
+          prim = traceKdReference<STATS>(S, Q, sd, RT_RAY_SHADOW, th, tc);
+        }
         if (prim != RT_PRIM_NONE) {
           const V3 Qh = Q + (th * sd);
           const double distanceSq = length2(Qh - Q);
@@ -464,7 +483,8 @@ k_intersect(DevScene S, int n, const double* rays, const int* types, RtHit* hits
   const int type = types ? types[i] : RT_RAY_VISIBILITY;
   TraceCounters tc{0, 0};
   double t;
-  const int prim = traceClosest<FAST, false>(S, p, d, type, 1.0e308, t, tc);
+  const int prim = FAST ? traceBvh<false, false>(S, p, d, type, 1.0e308, -1.0, t, tc)
+                        : traceKdReference<false>(S, p, d, type, t, tc);
   RtHit h;
   h.t = 1000.0;                      // scene.cpp:155
   h.N[0] = h.N[1] = h.N[2] = 0.0;
@@ -552,6 +572,29 @@ hipError_t upload(const T* host, size_t count, T** dev) {
 }
 
 inline int gridFor(long long n) { return (int)((n + kBlock - 1) / kBlock); }
+
+// Plain Gauss-Jordan inverse of a row-major 4x4 (only used to box transformed
+// meshes for the BVH, never for shading arithmetic).
+void invert4(const double* m, double* out) {
+  double a[4][8];
+  for (int r = 0; r < 4; r++)
+    for (int c = 0; c < 4; c++) { a[r][c] = m[4 * r + c]; a[r][4 + c] = (r == c) ? 1.0 : 0.0; }
+  for (int c = 0; c < 4; c++) {
+    int piv = c;
+    for (int r = c + 1; r < 4; r++) if (std::fabs(a[r][c]) > std::fabs(a[piv][c])) piv = r;
+    for (int k = 0; k < 8; k++) std::swap(a[c][k], a[piv][k]);
+    const double s = a[c][c];
+    if (s == 0.0) continue;
+    for (int k = 0; k < 8; k++) a[c][k] /= s;
+    for (int r = 0; r < 4; r++) {
+      if (r == c) continue;
+      const double f = a[r][c];
+      for (int k = 0; k < 8; k++) a[r][k] -= f * a[c][k];
+    }
+  }
+  for (int r = 0; r < 4; r++)
+    for (int c = 0; c < 4; c++) out[4 * r + c] = a[r][4 + c];
+}
 
 }  // namespace
 
@@ -919,6 +962,12 @@ int rt_scene_create(const RtSceneDesc* d, RtScene** out) {
   }
   // triangles with the ray-independent terms of TrimeshFace::intersectLocal
   {
+    std::vector<char> ownerIdentity((size_t)d->n_objects, 0);
+    for (int i = 0; i < d->n_objects; i++) {
+      bool id = true;
+      for (int k = 0; k < 16; k++) id = id && d->objects[i].inverse[k] == ((k % 5 == 0) ? 1.0 : 0.0);
+      ownerIdentity[i] = id;
+    }
     std::vector<DevTri> tris((size_t)d->n_faces);
     std::vector<int> ids((size_t)d->n_faces * 3);
     for (int m = 0; m < d->n_meshes; m++) {
@@ -941,17 +990,83 @@ int rt_scene_create(const RtSceneDesc* d, RtScene** out) {
         if (na0 >= na1 && na0 >= na2) { ax = 1; ay = 2; }
         else if (na1 >= na0 && na1 >= na2) { ax = 0; ay = 2; }
         else { ax = 0; ay = 1; }
-        T.axes = ax | (ay << 2);
+        T.axes = ax | (ay << 2) | (ownerIdentity[M.object] ? 16 : 0);
         const double z = (T.v1[ax] - T.v0[ax]) * (T.v2[ay] - T.v0[ay]) -
                          (T.v1[ay] - T.v0[ay]) * (T.v2[ax] - T.v0[ax]);
         T.abc = std::fabs(z) / 2;
         T.object_id = F.object_id;
         T.owner = M.object;
-        T._pad = 0;
+        T.face = fi;
       }
     }
     DevTri* p; HIP_TRY(upload(tris.data(), tris.size(), &p)); keep(p); D.tris = p;
     int* q; HIP_TRY(upload(ids.data(), ids.size(), &q)); keep(q); D.face_ids = q;
+
+    // ---- the library's own BVH over world-space triangle and object boxes
+    if ((size_t)d->n_faces >= (1u << 27)) return fail(RT_ERR_UNSUPPORTED, "too many triangles for the BVH leaf encoding");
+    std::vector<rtbvh::Prim> prims;
+    prims.reserve((size_t)d->n_faces + d->n_objects);
+    for (int oi = 0; oi < d->n_objects; oi++) {
+      const RtObject& o = d->objects[oi];
+      if (o.kind != RT_OBJ_TRIMESH) {
+        rtbvh::Prim pr;
+        for (int a = 0; a < 3; a++) {
+          pr.box.lo[a] = o.bbox_min[a];
+          pr.box.hi[a] = o.bbox_max[a];
+          pr.c[a] = 0.5 * (o.bbox_min[a] + o.bbox_max[a]);
+        }
+        pr.id = rtbvh::kObjectBit | oi;
+        prims.push_back(pr);
+        continue;
+      }
+      const RtMesh& M = d->meshes[o.mesh];
+      double xf[16];
+      if (!ownerIdentity[oi]) invert4(o.inverse, xf);
+      for (int f = 0; f < M.n_faces; f++) {
+        const DevTri& T = tris[M.first_face + f];
+        rtbvh::Prim pr;
+        pr.box.reset();
+        const double* vs[3] = {T.v0, T.v1, T.v2};
+        for (int k = 0; k < 3; k++) {
+          double w[3] = {vs[k][0], vs[k][1], vs[k][2]};
+          if (!ownerIdentity[oi])
+            for (int r = 0; r < 3; r++)
+              w[r] = xf[4 * r] * vs[k][0] + xf[4 * r + 1] * vs[k][1] + xf[4 * r + 2] * vs[k][2] + xf[4 * r + 3];
+          pr.box.grow(w);
+        }
+        if (!ownerIdentity[oi]) {
+          // the forward transform is a numerical inverse of the given inverse: pad
+          for (int a = 0; a < 3; a++) {
+            const double e = 1e-9 * (std::fabs(pr.box.lo[a]) + std::fabs(pr.box.hi[a]) + 1e-30);
+            pr.box.lo[a] -= e;
+            pr.box.hi[a] += e;
+          }
+        }
+        for (int a = 0; a < 3; a++) pr.c[a] = 0.5 * (pr.box.lo[a] + pr.box.hi[a]);
+        pr.id = M.first_face + f;
+        prims.push_back(pr);
+      }
+    }
+    rtbvh::Builder bvh;
+    D.bvh_valid = bvh.build(prims) ? 1 : 0;
+    if (D.bvh_valid) {
+      if (bvh.maxDepth + 2 > RT_BVH_STACK) return fail(RT_ERR_UNSUPPORTED, "BVH deeper than the traversal stack allows");
+      std::vector<DevTri> ordered(bvh.triOrder.size());
+      for (size_t i = 0; i < ordered.size(); i++) {
+        if (bvh.triOrder[i] & rtbvh::kObjectBit) std::memset(&ordered[i], 0, sizeof(DevTri));
+        else ordered[i] = tris[bvh.triOrder[i]];
+      }
+      DevTri* bt; HIP_TRY(upload(ordered.data(), ordered.size(), &bt)); keep(bt); D.bvhTris = bt;
+      static_assert(sizeof(rtbvh::Node) == sizeof(DevBvhNode), "BVH node layouts differ");
+      DevBvhNode* bn;
+      HIP_TRY(upload(reinterpret_cast<const DevBvhNode*>(bvh.nodes.data()), bvh.nodes.size(), &bn));
+      keep(bn);
+      D.bvh = bn;
+      for (int a = 0; a < 3; a++) {
+        D.bvh_bb_min[a] = bvh.rootBox.lo[a];
+        D.bvh_bb_max[a] = bvh.rootBox.hi[a];
+      }
+    }
   }
   { RtObject* p; HIP_TRY(upload(d->objects, (size_t)d->n_objects, &p)); keep(p); D.objects = p; }
   { RtMesh* p; HIP_TRY(upload(d->meshes, (size_t)d->n_meshes, &p)); keep(p); D.meshes = p; }
@@ -977,6 +1092,9 @@ int rt_scene_create(const RtSceneDesc* d, RtScene** out) {
     D.scene_bb_min[k] = d->scene_bb_min[k];
     D.scene_bb_max[k] = d->scene_bb_max[k];
   }
+  D.opaque = 1;
+  for (int m = 0; m < d->n_materials; m++)
+    if (d->materials[m].kt[0] != 0 || d->materials[m].kt[1] != 0 || d->materials[m].kt[2] != 0) D.opaque = 0;
   D.n_objects = d->n_objects;
   D.n_lights = d->n_lights;
   D.scene_root = d->scene_kd_root;

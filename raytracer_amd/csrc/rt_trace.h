@@ -2,12 +2,14 @@
 //
 // Closest-hit query = Scene::intersect (src/scene/scene.cpp:133-159).  Two
 // flavours share the primitive arithmetic:
-//   REFERENCE  Scene::intersectKdTree's exact push rules, far child first, no
-//              early exit, per-candidate bounding-box cull through
-//              Geometry::intersect (scene.cpp:59-129,13-36).
-//   FAST       near child first, entries culled once their interval starts
-//              beyond the best hit, intervals kept as outward-rounded floats,
-//              no per-face box cull, barycentric acceptance without divisions.
+//   REFERENCE  the caller's KD-trees walked with Scene::intersectKdTree's exact
+//              push rules, far child first, no early exit, per-candidate
+//              bounding-box cull through Geometry::intersect
+//              (scene.cpp:59-129,13-36).
+//   FAST       the library's own bounding-volume hierarchy (rt_bvh.h), near
+//              child first, subtrees culled once they start beyond the best
+//              hit, no per-face box cull, barycentric acceptance without
+//              divisions, optional any-hit termination for shadow rays.
 // Both compute t of an accepted hit with the same operations, so when they pick
 // the same primitive the hit is bit-identical.
 #pragma once
@@ -36,11 +38,19 @@ struct DevTri {
   double n[3];
   double dconst;
   double abc;
-  int axes;       // ax | (ay << 2)
+  int axes;       // ax | (ay << 2) | (16 if the owner's transform is the identity)
   int object_id;  // Geometry::objectID of the face
   int owner;      // index of the owning Trimesh in objects[]
-  int _pad;
+  int face;       // global face index (position in the caller's faces[] array)
 };
+
+// 64-byte BVH node, see rt_bvh.h for the child encoding.
+struct DevBvhNode {
+  float lo[2][3], hi[2][3];
+  int child[2];
+  int pad[2];
+};
+#define RT_BVH_OBJECT_BIT 0x40000000
 
 struct DevScene {
   const DevNode* nodes;
@@ -58,6 +68,12 @@ struct DevScene {
   double eye[3], look[3], u[3], v[3], ambient[3];
   double scene_bb_min[3], scene_bb_max[3];
   int n_objects, n_lights, scene_root, use_kd, cull, smooth;
+  // library-built BVH (RT_TRAVERSE_FAST)
+  const DevBvhNode* bvh;
+  const DevTri* bvhTris;     // triangles in leaf order
+  double bvh_bb_min[3], bvh_bb_max[3];
+  int bvh_valid;             // 0: empty scene
+  int opaque;                // 1: no material transmits (kt == 0 everywhere)
 };
 
 #define RT_PRIM_NONE (-1)
@@ -345,25 +361,13 @@ __device__ __forceinline__ bool faceBoxCull(const DevTri& T, const V3& p, const 
 #define RT_STACK_DEPTH 96
 #define RT_ENTRY_RESUME 0x80000000u
 
-template <bool FAST> struct StackEntry;
-template <> struct StackEntry<false> { uint32_t node; double tmin, tmax; };
-template <> struct StackEntry<true> { uint32_t node; float tmin, tmax; };
+struct KdEntry { uint32_t node; double tmin, tmax; };
 
-__device__ __forceinline__ float roundDown(double x) {
-  float f = (float)x;
-  return ((double)f > x) ? nextafterf(f, -INFINITY) : f;
-}
-__device__ __forceinline__ float roundUp(double x) {
-  float f = (float)x;
-  return ((double)f < x) ? nextafterf(f, INFINITY) : f;
-}
-
-// Scene::intersect.  Returns the winning primitive (RT_PRIM_NONE on a miss)
-// and its world-space t.  `tLimit` (FAST only) bounds the search: hits beyond
-// it are of no interest to the caller (shadow rays towards a positional light).
-template <bool FAST, bool STATS>
-__device__ int traceClosest(const DevScene& S, const V3& p, const V3& d, int rayType, double tLimit,
-                            double& tOut, TraceCounters& cnt) {
+// Scene::intersect with the reference's own traversal.  Returns the winning
+// primitive (RT_PRIM_NONE on a miss) and its world-space t.
+template <bool STATS>
+__device__ int traceKdReference(const DevScene& S, const V3& p, const V3& d, int rayType,
+                                double& tOut, TraceCounters& cnt) {
   bool haveOne = false;
   double bestT = 0.0;
   int bestPrim = RT_PRIM_NONE;
@@ -408,29 +412,17 @@ __device__ int traceClosest(const DevScene& S, const V3& p, const V3& d, int ray
     return bestPrim;
   }
 
-  StackEntry<FAST> stack[RT_STACK_DEPTH];
+  KdEntry stack[RT_STACK_DEPTH];
   int sp = 0;
   // function-level interval of the reference's current intersectKdTree call
-  double fMin = 0.0, fMax = 0.0, sceneFMin, sceneFMax;
-  {
-    bool hitBox = boxIntersect(S.scene_bb_min, S.scene_bb_max, p, d, fMin, fMax);
-    if (FAST) {
-      if (!hitBox) { tOut = 0.0; return RT_PRIM_NONE; }
-      if (fMin < 0.0) fMin = 0.0;
-      if (fMax > tLimit) fMax = tLimit;
-      stack[sp].tmin = roundDown(fMin);
-      stack[sp].tmax = roundUp(fMax);
-    } else {
-      stack[sp].tmin = fMin;
-      stack[sp].tmax = fMax;
-    }
-    stack[sp].node = (uint32_t)S.scene_root;
-    sp++;
-  }
-  sceneFMin = fMin;
-  sceneFMax = fMax;
+  double fMin = 0.0, fMax = 0.0;
+  boxIntersect(S.scene_bb_min, S.scene_bb_max, p, d, fMin, fMax);  // result ignored (scene.cpp:139)
+  stack[sp].node = (uint32_t)S.scene_root;
+  stack[sp].tmin = fMin;
+  stack[sp].tmax = fMax;
+  sp++;
+  const double sceneFMin = fMin, sceneFMax = fMax;
   bool inMesh = false;
-  int meshOwner = -1;
   LocalRay lr;
   lr.len = 1.0;
 
@@ -441,14 +433,12 @@ __device__ int traceClosest(const DevScene& S, const V3& p, const V3& d, int ray
     if (nidx & RT_ENTRY_RESUME) {
       // back in the scene-level leaf loop after a nested mesh traversal
       nidx &= ~RT_ENTRY_RESUME;
-      k0 = FAST ? (int)stack[sp].tmin : (int)stack[sp].tmin;
+      k0 = (int)stack[sp].tmin;
       inMesh = false;
       fMin = sceneFMin;
       fMax = sceneFMax;
-    } else if (FAST) {
-      if (haveOne && (double)stack[sp].tmin > bestT) continue;
     }
-    const double eMin = (double)stack[sp].tmin, eMax = (double)stack[sp].tmax;
+    const double eMin = stack[sp].tmin, eMax = stack[sp].tmax;
     const DevNode nd = S.nodes[nidx];
     if (STATS) cnt.nodes++;
     if ((nd.a & 3u) == 3u) {
@@ -460,25 +450,18 @@ __device__ int traceClosest(const DevScene& S, const V3& p, const V3& d, int ray
           if (o.kind == RT_OBJ_TRIMESH) {
             const RtMesh& m = S.meshes[o.mesh];
             double a0 = 0.0, a1 = 0.0;
-            bool hitBox = boxIntersect(m.root_bb_min, m.root_bb_max, p, d, a0, a1);
+            boxIntersect(m.root_bb_min, m.root_bb_max, p, d, a0, a1);  // result ignored (scene.cpp:79)
             if (m.kd_root < 0) continue;
-            if (FAST) {
-              if (!hitBox) continue;
-              if (a0 < 0.0) a0 = 0.0;
-              if (a1 > tLimit) a1 = tLimit;
-              if (haveOne && a0 > bestT) continue;
-            }
             if (sp + 2 > RT_STACK_DEPTH) continue;
             stack[sp].node = nidx | RT_ENTRY_RESUME;
             stack[sp].tmin = (k + 1);
             stack[sp].tmax = 0;
             sp++;
             stack[sp].node = (uint32_t)m.kd_root;
-            if (FAST) { stack[sp].tmin = roundDown(a0); stack[sp].tmax = roundUp(a1); }
-            else { stack[sp].tmin = a0; stack[sp].tmax = a1; }
+            stack[sp].tmin = a0;
+            stack[sp].tmax = a1;
             sp++;
             inMesh = true;
-            meshOwner = oi;
             fMin = a0;
             fMax = a1;
             lr = toLocal(o.inverse, p, d);
@@ -496,11 +479,9 @@ __device__ int traceClosest(const DevScene& S, const V3& p, const V3& d, int ray
           const int fi = S.items[first + k];
           const DevTri& T = S.tris[fi];
           if (STATS) cnt.prims++;
-          if (!FAST) {
-            if (!faceBoxCull(T, p, d)) continue;
-          }
+          if (!faceBoxCull(T, p, d)) continue;
           double rt;
-          if (triTest<FAST>(T, lr.p, lr.d, cullBack, rt, nullptr)) {
+          if (triTest<false>(T, lr.p, lr.d, cullBack, rt, nullptr)) {
             double tw = rt / lr.len;
             if (!haveOne || tw < bestT) { haveOne = true; bestT = tw; bestPrim = RT_PRIM_FACE | fi; }
           }
@@ -511,42 +492,146 @@ __device__ int traceClosest(const DevScene& S, const V3& p, const V3& d, int ray
       const uint32_t left = nd.a >> 2, right = nd.b;
       const double po = p.get(dim), di = d.get(dim);
       const double tStar = (nd.split - po) / di;
-      if (!FAST) {
-        // scene.cpp:96-124: pushed intervals come from the function-level
-        // tMin/tMax, not from the popped element
-        uint32_t nearN, farN;
-        if (po < nd.split) { nearN = left; farN = right; } else { nearN = right; farN = left; }
-        if (sp + 2 > RT_STACK_DEPTH) continue;
-        if (tStar > eMax || tStar < 0) {
-          stack[sp].node = nearN; stack[sp].tmin = fMin; stack[sp].tmax = fMax; sp++;
-        } else if (tStar < eMin) {
-          stack[sp].node = farN; stack[sp].tmin = fMin; stack[sp].tmax = fMax; sp++;
-        } else if (eMin <= tStar && tStar <= eMax) {
-          stack[sp].node = nearN; stack[sp].tmin = fMin; stack[sp].tmax = tStar; sp++;
-          stack[sp].node = farN; stack[sp].tmin = tStar; stack[sp].tmax = fMax; sp++;
-        }
-      } else {
-        // near side by origin; an origin exactly on the plane belongs to the
-        // side the ray moves into
-        const bool leftNear = (po < nd.split) || (po == nd.split && di < 0);
-        const uint32_t nearN = leftNear ? left : right, farN = leftNear ? right : left;
-        if (sp + 2 > RT_STACK_DEPTH) continue;
-        if (tStar != tStar) {  // ray inside the split plane: both sides, same interval
-          stack[sp].node = farN; stack[sp].tmin = (float)eMin; stack[sp].tmax = (float)eMax; sp++;
-          stack[sp].node = nearN; stack[sp].tmin = (float)eMin; stack[sp].tmax = (float)eMax; sp++;
-        } else if (tStar > eMax || tStar <= 0) {
-          stack[sp].node = nearN; stack[sp].tmin = (float)eMin; stack[sp].tmax = (float)eMax; sp++;
-        } else if (tStar < eMin) {
-          stack[sp].node = farN; stack[sp].tmin = (float)eMin; stack[sp].tmax = (float)eMax; sp++;
-        } else {
-          stack[sp].node = farN; stack[sp].tmin = roundDown(tStar); stack[sp].tmax = (float)eMax; sp++;
-          stack[sp].node = nearN; stack[sp].tmin = (float)eMin; stack[sp].tmax = roundUp(tStar); sp++;
-        }
+      // scene.cpp:96-124: pushed intervals come from the function-level
+      // tMin/tMax, not from the popped element
+      uint32_t nearN, farN;
+      if (po < nd.split) { nearN = left; farN = right; } else { nearN = right; farN = left; }
+      if (sp + 2 > RT_STACK_DEPTH) continue;
+      if (tStar > eMax || tStar < 0) {
+        stack[sp].node = nearN; stack[sp].tmin = fMin; stack[sp].tmax = fMax; sp++;
+      } else if (tStar < eMin) {
+        stack[sp].node = farN; stack[sp].tmin = fMin; stack[sp].tmax = fMax; sp++;
+      } else if (eMin <= tStar && tStar <= eMax) {
+        stack[sp].node = nearN; stack[sp].tmin = fMin; stack[sp].tmax = tStar; sp++;
+        stack[sp].node = farN; stack[sp].tmin = tStar; stack[sp].tmax = fMax; sp++;
       }
     }
   }
-  (void)meshOwner;
   tOut = bestT;
+  return bestPrim;
+}
+
+// -------------------------------------------------------------- BVH traversal
+#define RT_BVH_STACK 64
+
+struct BvhEntry { int ref; float tn; };
+
+__device__ __forceinline__ float roundDownF(double x) {
+  float f = (float)x;
+  return ((double)f > x) ? nextafterf(f, -INFINITY) : f;
+}
+
+// Slab test of one child box (float, rounded outward at build time) in double
+// arithmetic.  fmin/fmax drop the NaN of 0 * inf when the origin lies on a slab
+// plane of an axis the ray is parallel to.
+__device__ __forceinline__ bool bvhChildHit(const DevBvhNode& n, int c, const V3& p, const V3& inv,
+                                            double tMaxCull, double& tn) {
+  const double x0 = ((double)n.lo[c][0] - p.x) * inv.x, x1 = ((double)n.hi[c][0] - p.x) * inv.x;
+  const double y0 = ((double)n.lo[c][1] - p.y) * inv.y, y1 = ((double)n.hi[c][1] - p.y) * inv.y;
+  const double z0 = ((double)n.lo[c][2] - p.z) * inv.z, z1 = ((double)n.hi[c][2] - p.z) * inv.z;
+  const double tnear = fmax(fmax(fmin(x0, x1), fmin(y0, y1)), fmax(fmin(z0, z1), 0.0));
+  const double tfar = fmin(fmin(fmax(x0, x1), fmax(y0, y1)), fmin(fmax(z0, z1), tMaxCull));
+  tn = tnear;
+  return tnear <= tfar * 1.000000000001;
+}
+
+// Closest hit (ANYHIT false) or occlusion query (ANYHIT true) on the library's
+// BVH.  Closest hit: returns the primitive and t like traceKdReference; hits
+// beyond tLimit are of no interest.  Occlusion: returns 0 as soon as any hit
+// satisfies the reference's occlusion test |(p + t d) - p|^2 < occDist2
+// (light.cpp:77-80,123-126; occDist2 < 0: any hit counts, light.cpp:21), else
+// RT_PRIM_NONE.
+template <bool ANYHIT, bool STATS>
+__device__ int traceBvh(const DevScene& S, const V3& p, const V3& d, int rayType, double tLimit,
+                        double occDist2, double& tOut, TraceCounters& cnt) {
+  tOut = 0.0;
+  if (!S.bvh_valid) return RT_PRIM_NONE;
+  {
+    double t0, t1;
+    if (!boxIntersect(S.bvh_bb_min, S.bvh_bb_max, p, d, t0, t1)) return RT_PRIM_NONE;
+  }
+  const bool cullBack = S.cull && rayType != RT_RAY_REFRACTION;
+  const V3 inv(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
+  // object-space ray of every identity-transform mesh (Geometry::intersect,
+  // scene.cpp:17-20): position is unchanged, direction is ((p+d)-p) renormalised
+  const V3 dirI = (p + d) - p;
+  const double lenI = length(dirI);
+  const V3 ldI(dirI.x / lenI, dirI.y / lenI, dirI.z / lenI);
+
+  bool haveOne = false;
+  double bestT = tLimit;   // doubles as the far cull bound until a hit exists
+  int bestPrim = RT_PRIM_NONE;
+  BvhEntry stack[RT_BVH_STACK];
+  int sp = 0;
+  int ref = 0;
+  for (;;) {
+    if (ref >= 0) {
+      const DevBvhNode n = S.bvh[ref];
+      if (STATS) cnt.nodes++;
+      double tn0, tn1;
+      const bool h0 = bvhChildHit(n, 0, p, inv, bestT, tn0);
+      const bool h1 = bvhChildHit(n, 1, p, inv, bestT, tn1) && n.child[1] != n.child[0];
+      if (h0 && h1) {
+        const bool firstIs0 = tn0 <= tn1;
+        if (sp < RT_BVH_STACK) {
+          stack[sp].ref = firstIs0 ? n.child[1] : n.child[0];
+          stack[sp].tn = roundDownF(firstIs0 ? tn1 : tn0);
+          sp++;
+        }
+        ref = firstIs0 ? n.child[0] : n.child[1];
+        continue;
+      }
+      if (h0) { ref = n.child[0]; continue; }
+      if (h1) { ref = n.child[1]; continue; }
+    } else {
+      const int x = ~ref;
+      if (x & RT_BVH_OBJECT_BIT) {
+        const int oi = x & 0x3fffffff;
+        double t;
+        V3 N;
+        if (STATS) cnt.prims++;
+        if (objectIntersect<false>(S.objects[oi], p, d, t, N)) {
+          if (ANYHIT) {
+            const V3 Qh = p + (t * d);
+            if (occDist2 < 0.0 || length2(Qh - p) < occDist2) { tOut = t; return 0; }
+          } else if (!haveOne || t < bestT) {
+            haveOne = true; bestT = t; bestPrim = oi;
+          }
+        }
+      } else {
+        const int first = x >> 3, count = (x & 7) + 1;
+        for (int k = 0; k < count; k++) {
+          const DevTri& T = S.bvhTris[first + k];
+          if (STATS) cnt.prims++;
+          double rt, tw;
+          bool hit;
+          if (T.axes & 16) {
+            hit = triTest<true>(T, p, ldI, cullBack, rt, nullptr);
+            tw = rt / lenI;
+          } else {
+            const LocalRay lr = toLocal(S.objects[T.owner].inverse, p, d);
+            hit = triTest<true>(T, lr.p, lr.d, cullBack, rt, nullptr);
+            tw = rt / lr.len;
+          }
+          if (!hit) continue;
+          if (ANYHIT) {
+            const V3 Qh = p + (tw * d);
+            if (occDist2 < 0.0 || length2(Qh - p) < occDist2) { tOut = tw; return 0; }
+          } else if (!haveOne || tw < bestT) {
+            haveOne = true; bestT = tw; bestPrim = RT_PRIM_FACE | T.face;
+          }
+        }
+      }
+    }
+    // pop the next subtree that can still contain a closer hit
+    bool found = false;
+    while (sp > 0) {
+      --sp;
+      if ((double)stack[sp].tn <= bestT) { ref = stack[sp].ref; found = true; break; }
+    }
+    if (!found) break;
+  }
+  tOut = haveOne ? bestT : 0.0;
   return bestPrim;
 }
 
