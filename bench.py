@@ -172,10 +172,11 @@ def main():
     elapsed = float(tvals[0])
     total_rays, total_trace_ms, total_launches, total_dev_ms = [float(x) for x in cvals.tolist()]
 
-    # Untimed pass with device counters: kd nodes visited (V) and primitives
+    # Untimed pass with device counters: tree nodes visited (V) and primitives
     # tested (T) of this rank's shard, for the algorithmic byte count
-    # B_ray = 16 V + 128 T + 160 (16 B node record, 128 B triangle record, a
-    # 80 B ray record written and read once through the level queues).
+    # B_ray = node_bytes V + 128 T + 160 (node record: 64 B BVH node on the fast
+    # path, 16 B KD node on the reference path; 128 B triangle record; an 80 B
+    # ray record written and read once through the level queues).
     roof = None
     if not args.no_stats_pass:
         ps, keep2 = host.render_params(width, height, traversal=trav, tile_w=TILE, tile_h=TILE,
@@ -187,7 +188,8 @@ def main():
         if world > 1:
             dist.all_reduce(svals, op=dist.ReduceOp.SUM)
         V, T, R = [float(x) for x in svals.tolist()]
-        frame_bytes = 16.0 * V + 128.0 * T + 160.0 * R
+        node_bytes = 64.0 if args.traversal == "fast" else 16.0
+        frame_bytes = node_bytes * V + 128.0 * T + 160.0 * R
         # per step: all ranks' traversal launches and their summed device time
         bytes_per_launch = frame_bytes * args.steps / max(total_launches, 1.0)
         ms_per_launch = total_trace_ms / max(total_launches, 1.0)
@@ -199,7 +201,9 @@ def main():
                 traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        roof = {"bound": "hbm", "kernel": "k_trace + k_lights (two-level KD traversal)",
+        roof = {"bound": "hbm", "kernel": "k_trace + k_lights (%s)" % (
+                    "BVH closest-hit / any-hit traversal" if args.traversal == "fast" else "reference KD traversal"),
+                "bytes_per_ray": round(frame_bytes / max(R, 1.0), 1),
                 "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                 "bytes_per_launch": round(bytes_per_launch), "ms_per_launch": round(ms_per_launch, 4),

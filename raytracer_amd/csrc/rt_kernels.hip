@@ -172,68 +172,127 @@ k_trace(DevScene S, int n, const double* rayP, const double* rayD, const int* ra
   if (STATS) flushCounters(tc, counters);
 }
 
-// Append helper: all lanes of the wave that reach it get consecutive indices.
-__device__ __forceinline__ unsigned int waveAppend(bool want, unsigned int* counter) {
-  const unsigned long long mask = __ballot(want);
-  if (!want) return 0xffffffffu;
+// ---- queue compaction without a hot atomic ----------------------------------
+// A block owns a tile of kBlock * items consecutive queue entries (thread t
+// handles entries tileBase + k*kBlock + t, k < items <= kMaxItems).  Pass 1
+// counts the entries that want a slot per (k, wave), one thread turns the counts
+// into exclusive offsets and reserves the tile's total with ONE atomic, pass 2
+// hands out the slots.  A single device-wide counter saturates near 90 M
+// atomics/s on this chip, so one atomic per wavefront (what a ballot-append
+// does) would cost tens of milliseconds per 4K frame.
+constexpr int kMaxItems = 16;
+constexpr int kWaves = kBlock / 64;
+
+struct TileScan {
+  unsigned int cnt[2][kMaxItems][kWaves];   // [class][item][wave]
+  unsigned int base[2];                     // global offset of the tile per class
+};
+
+// Pass 1 for one item: record how many lanes of this wave raise flag(s).
+__device__ __forceinline__ void tileCount(TileScan& ts, int cls, int k, bool flag) {
+  const unsigned long long m = __ballot(flag);
+  if ((threadIdx.x & 63) == 0) ts.cnt[cls][k][threadIdx.x >> 6] = (unsigned int)__popcll(m);
+}
+
+// Between the passes: exclusive scan of the counts (class 0 first, then class
+// 1), one atomicAdd of the total on *counter.  Returns the totals per class.
+__device__ __forceinline__ void tileReserve(TileScan& ts, int items, int classes, unsigned int* counter,
+                                            unsigned int& total0, unsigned int& total1) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned int run = 0;
+    for (int c = 0; c < classes; c++) {
+      const unsigned int start = run;
+      for (int k = 0; k < items; k++)
+        for (int w = 0; w < kWaves; w++) {
+          const unsigned int v = ts.cnt[c][k][w];
+          ts.cnt[c][k][w] = run;
+          run += v;
+        }
+      ts.base[c] = run - start;   // class total, replaced by the global base below
+    }
+    const unsigned int t0 = ts.base[0], t1 = (classes > 1) ? ts.base[1] : 0;
+    const unsigned int g = run ? atomicAdd(counter, run) : 0;
+    ts.base[0] = g;
+    ts.base[1] = g;
+    total0 = t0;
+    total1 = t1;
+  }
+  __syncthreads();
+}
+
+// Pass 2 for one item: slot of this lane if it raises the flag.
+__device__ __forceinline__ unsigned int tileSlot(const TileScan& ts, int cls, int k, bool flag) {
+  const unsigned long long m = __ballot(flag);
   const int lane = threadIdx.x & 63;
-  const unsigned int prefix = __popcll(mask & ((1ull << lane) - 1ull));
-  const int leader = __ffsll((long long)mask) - 1;
-  unsigned int base = 0;
-  if (lane == leader) base = atomicAdd(counter, (unsigned int)__popcll(mask));
-  base = __shfl(base, leader);
-  return base + prefix;
+  return ts.base[cls] + ts.cnt[cls][k][threadIdx.x >> 6] + (unsigned int)__popcll(m & ((1ull << lane) - 1ull));
 }
 
 // Misses take the background (RayTracer.cpp:213-224); hits become shade points.
 __global__ void __launch_bounds__(kBlock)
-k_surface(DevScene S, int n, int par, size_t rayOff, size_t spOff, int level, int useCube,
+k_surface(DevScene S, int n, int items, int par, size_t rayOff, size_t spOff, int level, int useCube,
           int filterWidth, Pool P) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  bool isHit = false;
-  int type = -1, prim = RT_PRIM_NONE;
-  if (i < n) {
-    type = P.rayType[par][i];
-    prim = P.hitPrim[i];
-    isHit = type >= 0 && prim != RT_PRIM_NONE;
+  __shared__ TileScan ts;
+  __shared__ unsigned int litCount;
+  const int tileBase = blockIdx.x * kBlock * items;
+  if (threadIdx.x == 0) litCount = 0;
+  unsigned int hitMask = 0;
+  for (int k = 0; k < items; k++) {
+    const int i = tileBase + k * kBlock + threadIdx.x;
+    const bool hit = i < n && P.rayType[par][i] >= 0 && P.hitPrim[i] != RT_PRIM_NONE;
+    hitMask |= (hit ? 1u : 0u) << k;
+    tileCount(ts, 0, k, hit);
+  }
+  unsigned int tot0 = 0, tot1 = 0;
+  tileReserve(ts, items, 1, &P.counters->nsp, tot0, tot1);
+  unsigned int myLit = 0;
+  for (int k = 0; k < items; k++) {
+    const int i = tileBase + k * kBlock + threadIdx.x;
+    const bool isHit = (hitMask >> k) & 1u;
+    const unsigned int s = tileSlot(ts, 0, k, isHit);
+    if (i >= n) continue;
+    const int type = P.rayType[par][i];
     if (!isHit) {
       V3 bg(0.0, 0.0, 0.0);
       if (type >= 0 && useCube) bg = cubeColor(S, loadV3(P.rayD[par], P.cap, i), filterWidth);
       storeV3(P.rayI, P.cap, rayOff + i, bg);
       if (level == 0) P.primaryId[i] = 0;
+      continue;
     }
+    if (spOff + s >= P.cap) {
+      P.counters->overflow = 1;
+      continue;
+    }
+    const int prim = P.hitPrim[i];
+    const V3 p = loadV3(P.rayP[par], P.cap, i), d = loadV3(P.rayD[par], P.cap, i);
+    const double t = P.hitT[i];
+    Surface sf;
+    MatD m;
+    surfaceAt(S, prim, p, d, type, sf, &m, false);
+    if (level == 0) P.primaryId[i] = sf.objectID;
+    const V3 Q = p + (t * d);                                  // ray::at (ray.h:42-43)
+    const V3 base = m.ke + prod(m.ka, V3(S.ambient));          // material.cpp:46
+    const bool lit = !(iszero(m.kd) && iszero(m.ks));          // material.cpp:50-53
+    storeV3(P.spQ, P.cap, s, Q);
+    storeV3(P.spN, P.cap, s, sf.N);
+    storeV3(P.spKd, P.cap, s, m.kd);
+    storeV3(P.spKs, P.cap, s, m.ks);
+    P.spShin[s] = shininessOf(m);
+    P.spLit[s] = lit ? 1 : 0;
+    P.spRayLocal[s] = i;
+    const size_t g = spOff + s;
+    storeV3(P.spShade, P.cap, g, base);
+    storeV3(P.spKr, P.cap, g, m.kr);
+    storeV3(P.spKt, P.cap, g, m.kt);
+    P.spIor[g] = intensityValue(m.index);                      // Material::index (material.h:217)
+    P.spChildRefl[g] = -1;
+    P.spChildRefr[g] = -1;
+    P.spRayGlobal[g] = (int)(rayOff + i);
+    if (lit) myLit++;
   }
-  const unsigned int s = waveAppend(isHit, &P.counters->nsp);
-  if (!isHit) return;
-  if (spOff + s >= P.cap) {
-    P.counters->overflow = 1;
-    return;
-  }
-  const V3 p = loadV3(P.rayP[par], P.cap, i), d = loadV3(P.rayD[par], P.cap, i);
-  const double t = P.hitT[i];
-  Surface sf;
-  MatD m;
-  surfaceAt(S, prim, p, d, type, sf, &m, false);
-  if (level == 0) P.primaryId[i] = sf.objectID;
-  const V3 Q = p + (t * d);                                  // ray::at (ray.h:42-43)
-  const V3 base = m.ke + prod(m.ka, V3(S.ambient));          // material.cpp:46
-  const bool lit = !(iszero(m.kd) && iszero(m.ks));          // material.cpp:50-53
-  storeV3(P.spQ, P.cap, s, Q);
-  storeV3(P.spN, P.cap, s, sf.N);
-  storeV3(P.spKd, P.cap, s, m.kd);
-  storeV3(P.spKs, P.cap, s, m.ks);
-  P.spShin[s] = shininessOf(m);
-  P.spLit[s] = lit ? 1 : 0;
-  P.spRayLocal[s] = i;
-  const size_t g = spOff + s;
-  storeV3(P.spShade, P.cap, g, base);
-  storeV3(P.spKr, P.cap, g, m.kr);
-  storeV3(P.spKt, P.cap, g, m.kt);
-  P.spIor[g] = intensityValue(m.index);                      // Material::index (material.h:217)
-  P.spChildRefl[g] = -1;
-  P.spChildRefr[g] = -1;
-  P.spRayGlobal[g] = (int)(rayOff + i);
-  if (lit) atomicAdd(&P.counters->litsp, 1ull);
+  if (myLit) atomicAdd(&litCount, myLit);   // LDS atomic
+  __syncthreads();
+  if (threadIdx.x == 0 && litCount) atomicAdd(&P.counters->litsp, (unsigned long long)litCount);
 }
 
 // One thread per (light, shade point): shadow ray and the two Phong terms of
@@ -339,40 +398,82 @@ k_lights(DevScene S, long long nMax, Pool P) {
 }
 
 // In-order light sum of Material::shade, then the secondary rays of
-// RayTracer::traceRay (RayTracer.cpp:152-201).
+// RayTracer::traceRay (RayTracer.cpp:152-201).  Reflected rays of a tile are
+// queued before its refracted rays.
 __global__ void __launch_bounds__(kBlock)
-k_shade(DevScene S, int nMax, int par, size_t spOff, size_t nextRayOff, int depthLeft, Pool P) {
-  const int s = blockIdx.x * blockDim.x + threadIdx.x;
-  const unsigned int nsp = P.counters->nsp;
-  const bool on = s < nMax && (unsigned int)s < nsp;
-  const size_t g = spOff + (on ? s : 0);
-  bool wantRefl = false, wantRefr = false;
-  V3 Q, reflDir, refrDir;
-  if (on) {
-    V3 I = loadV3(P.spShade, P.cap, g);
-    if (P.spLit[s]) {
-      const bool hasKd = !iszero(loadV3(P.spKd, P.cap, s)), hasKs = !iszero(loadV3(P.spKs, P.cap, s));
-      for (int li = 0; li < S.n_lights; li++) {
-        const size_t o = (size_t)li * 3 * P.cap;
-        if (hasKd) I = I + loadV3(P.lightD + o, P.cap, s);
-        if (hasKs) I = I + loadV3(P.lightS + o, P.cap, s);
+k_shade(DevScene S, int nMax, int items, int par, size_t spOff, size_t nextRayOff, int depthLeft, Pool P) {
+  __shared__ TileScan ts;
+  const unsigned int nsp = min((unsigned int)nMax, P.counters->nsp);
+  const int tileBase = blockIdx.x * kBlock * items;
+  if ((unsigned int)tileBase >= nsp) return;   // whole block, uniform
+  // pass 1: light sum, and which children each shade point spawns
+  unsigned int reflMask = 0, refrMask = 0;
+  for (int k = 0; k < items; k++) {
+    const int s = tileBase + k * kBlock + threadIdx.x;
+    bool wantRefl = false, wantRefr = false;
+    if ((unsigned int)s < nsp) {
+      const size_t g = spOff + s;
+      if (P.spLit[s]) {
+        V3 I = loadV3(P.spShade, P.cap, g);
+        const bool hasKd = !iszero(loadV3(P.spKd, P.cap, s)), hasKs = !iszero(loadV3(P.spKs, P.cap, s));
+        for (int li = 0; li < S.n_lights; li++) {
+          const size_t o = (size_t)li * 3 * P.cap;
+          if (hasKd) I = I + loadV3(P.lightD + o, P.cap, s);
+          if (hasKs) I = I + loadV3(P.lightS + o, P.cap, s);
+        }
+        storeV3(P.spShade, P.cap, g, I);
       }
-      storeV3(P.spShade, P.cap, g, I);
+      if (depthLeft > 0) {
+        wantRefl = !iszero(loadV3(P.spKr, P.cap, g));
+        if (!iszero(loadV3(P.spKt, P.cap, g))) {
+          const V3 d = loadV3(P.rayD[par], P.cap, P.spRayLocal[s]);
+          const double cosineAngle = acos(dot(loadV3(P.spN, P.cap, s), d)) * 180 / M_PI;
+          wantRefr = cosineAngle < 360;  // RayTracer.cpp:173,195: false only for a NaN angle
+        }
+      }
     }
-    if (depthLeft > 0) {
-      const int ri = P.spRayLocal[s];
-      const V3 d = loadV3(P.rayD[par], P.cap, ri);
-      const V3 N = loadV3(P.spN, P.cap, s);
-      const V3 kr = loadV3(P.spKr, P.cap, g), kt = loadV3(P.spKt, P.cap, g);
-      Q = loadV3(P.spQ, P.cap, s);
-      const V3 minusD = -1 * d;
-      const V3 cosVector = N * dot(minusD, N);
-      const V3 sinVector = cosVector + d;
-      if (!iszero(kr)) {
-        reflDir = normalized(cosVector + sinVector);
-        wantRefl = true;
+    reflMask |= (wantRefl ? 1u : 0u) << k;
+    refrMask |= (wantRefr ? 1u : 0u) << k;
+    tileCount(ts, 0, k, wantRefl);
+    tileCount(ts, 1, k, wantRefr);
+  }
+  unsigned int nRefl = 0, nRefr = 0;
+  tileReserve(ts, items, 2, &P.counters->nnext, nRefl, nRefr);
+  if (threadIdx.x == 0) {
+    if (nRefl) atomicAdd(&P.counters->refl, (unsigned long long)nRefl);
+    if (nRefr) atomicAdd(&P.counters->refr, (unsigned long long)nRefr);
+  }
+  if (depthLeft <= 0) return;
+  // pass 2: generate the rays into their slots
+  const int np = par ^ 1;
+  for (int k = 0; k < items; k++) {
+    const int s = tileBase + k * kBlock + threadIdx.x;
+    const bool wantRefl = (reflMask >> k) & 1u, wantRefr = (refrMask >> k) & 1u;
+    const unsigned int a = tileSlot(ts, 0, k, wantRefl);
+    const unsigned int b = tileSlot(ts, 1, k, wantRefr);
+    if (!(wantRefl || wantRefr)) continue;
+    const size_t g = spOff + s;
+    const V3 d = loadV3(P.rayD[par], P.cap, P.spRayLocal[s]);
+    const V3 N = loadV3(P.spN, P.cap, s);
+    const V3 Q = loadV3(P.spQ, P.cap, s);
+    const V3 minusD = -1 * d;
+    const V3 cosVector = N * dot(minusD, N);
+    const V3 sinVector = cosVector + d;
+    if (wantRefl) {
+      if (nextRayOff + a >= P.cap) {
+        P.counters->overflow = 1;
+      } else {
+        const V3 reflDir = normalized(cosVector + sinVector);
+        storeV3(P.rayP[np], P.cap, a, Q);
+        storeV3(P.rayD[np], P.cap, a, reflDir);
+        P.rayType[np][a] = RT_RAY_REFLECTION;
+        P.spChildRefl[g] = (int)(nextRayOff + a);
       }
-      if (!iszero(kt)) {
+    }
+    if (wantRefr) {
+      if (nextRayOff + b >= P.cap) {
+        P.counters->overflow = 1;
+      } else {
         const double cosineAngle = acos(dot(N, d)) * 180 / M_PI;
         double n_i, n_r;
         int iDirection;
@@ -380,37 +481,12 @@ k_shade(DevScene S, int nMax, int par, size_t spOff, size_t nextRayOff, int dept
         else { n_i = P.spIor[g]; n_r = 1; iDirection = -1; }
         const V3 sinT = (n_i / n_r) * sinVector;
         const V3 cosT = (-1 * N) * sqrt(1 - dot(sinT, sinT));
-        if (cosineAngle < 360) {  // RayTracer.cpp:173,195: false only for a NaN angle
-          const V3 rd = normalized(cosT + (double)iDirection * sinT);
-          refrDir = (double)iDirection * rd;
-          wantRefr = true;
-        }
+        const V3 rd = normalized(cosT + (double)iDirection * sinT);
+        storeV3(P.rayP[np], P.cap, b, Q);
+        storeV3(P.rayD[np], P.cap, b, (double)iDirection * rd);
+        P.rayType[np][b] = RT_RAY_REFRACTION;
+        P.spChildRefr[g] = (int)(nextRayOff + b);
       }
-    }
-  }
-  const int np = par ^ 1;
-  const unsigned int a = waveAppend(wantRefl, &P.counters->nnext);
-  if (wantRefl) {
-    if (nextRayOff + a >= P.cap) {
-      P.counters->overflow = 1;
-    } else {
-      storeV3(P.rayP[np], P.cap, a, Q);
-      storeV3(P.rayD[np], P.cap, a, reflDir);
-      P.rayType[np][a] = RT_RAY_REFLECTION;
-      P.spChildRefl[g] = (int)(nextRayOff + a);
-      atomicAdd(&P.counters->refl, 1ull);
-    }
-  }
-  const unsigned int b = waveAppend(wantRefr, &P.counters->nnext);
-  if (wantRefr) {
-    if (nextRayOff + b >= P.cap) {
-      P.counters->overflow = 1;
-    } else {
-      storeV3(P.rayP[np], P.cap, b, Q);
-      storeV3(P.rayD[np], P.cap, b, refrDir);
-      P.rayType[np][b] = RT_RAY_REFRACTION;
-      P.spChildRefr[g] = (int)(nextRayOff + b);
-      atomicAdd(&P.counters->refr, 1ull);
     }
   }
 }
@@ -799,7 +875,10 @@ int renderBatch(RenderCtx& cx, long long first, int count) {
     else { if (cx.wantStats) launchTrace<false, true>(sc, n, par); else launchTrace<false, false>(sc, n, par); }
     if (timed) timedEnd(sc);
     cx.stats.trace_launches++;
-    k_surface<<<gridFor(n), kBlock, 0, sc->stream>>>(sc->dev, n, par, rayOff, spOff, level,
+    // entries per thread: enough tiles to fill the chip, few enough atomics
+    const int items = std::min(kMaxItems, std::max(1, n / (kBlock * 2048)));
+    const int tiles = (n + kBlock * items - 1) / (kBlock * items);
+    k_surface<<<tiles, kBlock, 0, sc->stream>>>(sc->dev, n, items, par, rayOff, spOff, level,
                                                      rp.use_cubemap && sc->dev.cube_w > 0,
                                                      rp.filter_width, P);
     const long long lightThreads = (long long)n * sc->dev.n_lights;
@@ -810,8 +889,8 @@ int renderBatch(RenderCtx& cx, long long first, int count) {
       if (timed2) timedEnd(sc);
       cx.stats.trace_launches++;
     }
-    k_shade<<<gridFor(n), kBlock, 0, sc->stream>>>(sc->dev, n, par, spOff, rayOff + n,
-                                                   rp.depth - level, P);
+    k_shade<<<tiles, kBlock, 0, sc->stream>>>(sc->dev, n, items, par, spOff, rayOff + n,
+                                              rp.depth - level, P);
     Counters c;
     HIP_TRY(hipMemcpyAsync(&c, P.counters, sizeof c, hipMemcpyDeviceToHost, sc->stream));
     HIP_TRY(hipStreamSynchronize(sc->stream));
