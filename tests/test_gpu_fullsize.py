@@ -1,0 +1,143 @@
+"""GPU tests at the sizes BASELINE.json names (C1..C5).  Full frames are far
+beyond what the CPU oracle renders in seconds, so each configuration is checked
+through (a) the oracle on a stratified pixel sample of the same frame, (b) the
+HIP reference-traversal path against the HIP fast path over the whole frame,
+and (c) size-independent properties: repeatability, shard assembly."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from raytracer_amd import abi, device, host, parallel, scenes
+from oracle import loader
+from tests import common
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _config(name):
+    cfg = scenes.CONFIGS[name]
+    w = cfg["width"]
+    h = scenes.frame_height(w, cfg["aspect"])
+    hs = host.HostScene(text=cfg["scene"](), kd_max_depth=cfg["kd_depth"])
+    if cfg["cubemap"]:
+        hs.set_cubemap(scenes.cube_map_faces(512, seed=3))
+    kw = dict(depth=cfg["depth"], use_cubemap=cfg["cubemap"])
+    if cfg["aa"]:
+        kw.update(aa_mode=abi.RT_AA_FULL, aa_samples=cfg["aa"], jitter=host.jitter_table(1234567, cfg["aa"]))
+    return hs, w, h, kw
+
+
+def _sample(w, h, count, seed):
+    rng = np.random.RandomState(seed)
+    return np.stack([rng.randint(0, w, size=count), rng.randint(0, h, size=count)], axis=1).astype(np.int32)
+
+
+def _check_sample(hs, w, h, kw, rgb, count, seed, exact=True):
+    """Oracle (reference traversal) on `count` random pixels of the frame."""
+    xy = _sample(w, h, count, seed)
+    p, keep = host.render_params(w, h, **kw)
+    ref, _ = loader.render_pixels(hs.desc_ptr, p, xy, threads=16)
+    got = rgb[xy[:, 1], xy[:, 0]].astype(np.int32)
+    d = np.abs(got - ref.astype(np.int32)).max(axis=1)
+    assert (d > 1).sum() <= 1e-3 * count, "%d of %d sampled pixels off by more than 1" % ((d > 1).sum(), count)
+    if exact:
+        assert (d > 0).sum() <= max(2, count // 1000), "%d of %d sampled pixels differ" % ((d > 0).sum(), count)
+
+
+def test_c1_full_frame_is_byte_identical(built):
+    hs, w, h, kw = _config("C1")
+    assert (w, h) == (512, 512)
+    ds = device.DeviceScene(hs.desc_ptr)
+    p, _ = host.render_params(w, h, traversal=abi.RT_TRAVERSE_REFERENCE, **kw)
+    rgb, hits, st = ds.render(p)
+    pf, _ = host.render_params(w, h, traversal=abi.RT_TRAVERSE_FAST, **kw)
+    frgb, fhits, fst = ds.render(pf)
+    ds.close()
+    ref, rhits, rst = loader.render(hs.desc_ptr, p, threads=16)
+    common.assert_parity(rgb, hits, ref, rhits, what="C1 reference traversal")
+    common.assert_parity(frgb, fhits, ref, rhits, what="C1 fast traversal")
+    assert st.rays_total == rst.rays_total == fst.rays_total
+
+
+def test_c2_mesh_1080p(built):
+    hs, w, h, kw = _config("C2")
+    assert (w, h) == (1920, 1080) and hs.desc.n_faces > 70000
+    ds = device.DeviceScene(hs.desc_ptr)
+    pf, _ = host.render_params(w, h, traversal=abi.RT_TRAVERSE_FAST, **kw)
+    pr, _ = host.render_params(w, h, traversal=abi.RT_TRAVERSE_REFERENCE, **kw)
+    f, fh, fst = ds.render(pf)
+    r, rh, rst = ds.render(pr)
+    ds.close()
+    common.assert_parity(f, fh, r, rh, what="C2 fast vs reference traversal")
+    assert fst.rays_total == rst.rays_total
+    _check_sample(hs, w, h, kw, r, 6000, seed=2)
+
+
+def test_c3_cornell_cubemap_aa_1080p(built):
+    hs, w, h, kw = _config("C3")
+    ds = device.DeviceScene(hs.desc_ptr)
+    pr, _ = host.render_params(w, h, traversal=abi.RT_TRAVERSE_REFERENCE, **kw)
+    pf, _ = host.render_params(w, h, traversal=abi.RT_TRAVERSE_FAST, **kw)
+    r, rh, rst = ds.render(pr)
+    f, fh, fst = ds.render(pf)
+    ds.close()
+    _check_sample(hs, w, h, kw, r, 3000, seed=3)
+    # Axis-aligned walls put secondary origins on KD split planes, where the
+    # reference's traversal drops hits that a closest-hit query finds; the fast
+    # path is compared at the north-star tolerance, not bit-exactly.
+    common.assert_parity(f, fh, r, rh, exact=False, what="C3 fast vs reference traversal")
+
+
+def test_c4_million_triangles_4k(built):
+    hs, w, h, kw = _config("C4")
+    assert (w, h) == (3840, 2160) and hs.desc.n_faces == 1002528
+    ds = device.DeviceScene(hs.desc_ptr)
+    pf, _ = host.render_params(w, h, traversal=abi.RT_TRAVERSE_FAST, **kw)
+    a, ah, ast = ds.render(pf)
+    b, bh, bst = ds.render(pf)
+    assert np.array_equal(a, b) and np.array_equal(ah, bh)        # repeatable, whatever the queue order
+    assert ast.rays_total == bst.rays_total > 3 * w * h
+    # interleaved shards assemble to the same frame
+    frame = np.zeros_like(a)
+    for s in range(4):
+        ps, _ = host.render_params(w, h, traversal=abi.RT_TRAVERSE_FAST, shard_index=s, shard_count=4, **kw)
+        ds.render_into(ps, frame)
+    assert np.array_equal(frame, a)
+    ds.close()
+    _check_sample(hs, w, h, kw, a, 1500, seed=4)
+
+
+def test_c5_many_lights_4k(built):
+    hs, w, h, kw = _config("C5")
+    assert hs.desc.n_lights == 64 and hs.desc.n_faces == 500000
+    ds = device.DeviceScene(hs.desc_ptr)
+    pf, _ = host.render_params(w, h, traversal=abi.RT_TRAVERSE_FAST, **kw)
+    a, ah, ast = ds.render(pf)
+    ds.close()
+    assert ast.rays_shadow == 64 * ast.shade_points               # one shadow ray per light per shade point
+    _check_sample(hs, w, h, kw, a, 400, seed=5)
+
+
+def test_cli_matches_the_oracle(built, tmp_path):
+    scene = tmp_path / "simple.ray"
+    scene.write_text(scenes.simple_scene())
+    out = tmp_path / "out.bmp"
+    exe = os.path.join(ROOT, "raytracer_amd", "ray")
+    for extra in ([], ["--reference-traversal"]):
+        res = subprocess.run([exe, "-r", "3", "-w", "200", str(scene), str(out)] + extra,
+                             capture_output=True, text=True, timeout=120)
+        assert res.returncode == 0, res.stderr
+        assert "total time" in res.stdout
+        img = host.read_bmp(str(out))
+        hs = host.HostScene(path=str(scene))
+        p, _ = host.render_params(200, 200, depth=3)
+        ref, _, _ = loader.render(hs.desc_ptr, p, threads=8)
+        off1, off0 = common.image_diff(img, ref)
+        assert off1 == 0 and off0 <= 2
+    bad = subprocess.run([exe, "-q", str(scene), str(out)], capture_output=True, text=True)
+    assert bad.returncode == 1 and "usage" in bad.stderr
+    missing = subprocess.run([exe, str(tmp_path / "nope.ray"), str(out)], capture_output=True, text=True)
+    assert missing.returncode == 1 and "Unable to load ray file" in missing.stderr
