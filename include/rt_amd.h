@@ -147,12 +147,17 @@ typedef struct RtSceneDesc {
   const unsigned char* cube_rgb[6];
 } RtSceneDesc;
 
-/* Traversal flavour for the KD path.
- *  RT_TRAVERSE_REFERENCE: the reference's push rules, far-child-first order,
- *    no early exit, per-candidate bounding-box cull (scene.cpp:59-129, 13-36).
- *  RT_TRAVERSE_FAST: near-first with early exit and float-rounded
- *    conservative intervals; same primitive arithmetic, so t/N of the winning
- *    hit are bit-identical whenever both find the same primitive. */
+/* Traversal flavour of Scene::intersect.
+ *  RT_TRAVERSE_REFERENCE: walks the caller's KD-trees with the reference's push
+ *    rules, far-child-first order, no early exit, per-candidate bounding-box
+ *    cull (scene.cpp:59-129, 13-36); results equal the reference's, including
+ *    the hits its split-plane rules miss.
+ *  RT_TRAVERSE_FAST: walks a bounding volume hierarchy that rt_scene_create
+ *    builds itself over all triangles and objects (4-wide nodes, quantised
+ *    child boxes), nearest child first, culling subtrees behind the closest
+ *    hit; shadow rays of scenes without transmissive materials stop at the
+ *    first occluder.  The primitive arithmetic is the same, so the closest hit
+ *    equals the reference's linear scan over all primitives (m_bKdTree off). */
 enum { RT_TRAVERSE_REFERENCE = 0, RT_TRAVERSE_FAST = 1 };
 
 enum { RT_AA_NONE = 0, RT_AA_FULL = 1, RT_AA_ADAPTIVE = 2 };

@@ -17,6 +17,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdint>
+#include <cstring>
 #include <future>
 #include <vector>
 
@@ -75,6 +76,7 @@ class Builder {
   std::vector<int32_t> triOrder;   // leaf order -> global face index
   Box rootBox;
   int maxDepth = 0;
+  bool balanced = false;   // median splits only: depth <= log2(n) + 1
 
   // prims is consumed (reordered).  Returns false for an empty scene.
   bool build(std::vector<Prim>& prims) {
@@ -144,7 +146,10 @@ class Builder {
     double ext = -1;
     for (int a = 0; a < 3; a++) if (cb.hi[a] - cb.lo[a] > ext) { ext = cb.hi[a] - cb.lo[a]; axis = a; }
     int mid = first + count / 2;
-    if (ext > 0) {
+    if (ext > 0 && balanced) {
+      std::nth_element(P.begin() + first, P.begin() + mid, P.begin() + first + count,
+                       [axis](const Prim& x, const Prim& y) { return x.c[axis] < y.c[axis]; });
+    } else if (ext > 0) {
       // binned SAH over the three axes
       double bestCost = DBL_MAX; int bestAxis = -1, bestBin = -1;
       for (int a = 0; a < 3; a++) {
@@ -213,6 +218,115 @@ class Builder {
         if (childNode[c] >= 0) buildNode(childNode[c], beg[c], cnt[c], depth + 1, parallelDepth + 1);
     }
   }
+};
+
+
+// 64-byte 4-wide node with 8-bit quantised child boxes.  Child box c spans
+// origin + q * 2^exp per axis (lower planes rounded down, upper planes rounded
+// up, so the decoded box always contains the builder's box).  child[c] uses the
+// encoding of Node::child; kEmptyChild marks an unused slot.
+struct Node4 {
+  float origin[3];
+  int8_t exp[3];
+  uint8_t pad0;
+  int32_t child[4];
+  uint8_t qlo[4][3];
+  uint8_t qhi[4][3];
+  uint8_t pad1[8];
+};
+static_assert(sizeof(Node4) == 64, "BVH4 node must be 64 bytes");
+constexpr int32_t kEmptyChild = 0x7fffffff;
+
+// Collapses the binary tree into 4-wide nodes: a node adopts the two children
+// of a binary node and keeps replacing its largest internal child by that
+// child's two children until it has four or only leaves are left.
+class Collapser {
+ public:
+  std::vector<Node4> nodes;
+  int maxDepth = 0;
+
+  void run(const std::vector<Node>& bin) {
+    bin_ = &bin;
+    nodes.clear();
+    nodes.reserve(bin.size() / 2 + 1);
+    nodes.emplace_back();
+    maxDepth = 0;
+    // explicit work list instead of recursion: (binary node, output slot, depth)
+    struct Job { int binNode; int out; int depth; };
+    std::vector<Job> jobs{{0, 0, 1}};
+    while (!jobs.empty()) {
+      Job j = jobs.back();
+      jobs.pop_back();
+      maxDepth = std::max(maxDepth, j.depth);
+      struct Kid { Box box; int32_t ref; };
+      std::vector<Kid> kids;
+      auto addKids = [&](int b) {
+        const Node& n = (*bin_)[b];
+        for (int c = 0; c < 2; c++) {
+          if (c == 1 && n.child[1] == n.child[0]) continue;  // single-primitive scene
+          Kid k;
+          for (int a = 0; a < 3; a++) { k.box.lo[a] = n.lo[c][a]; k.box.hi[a] = n.hi[c][a]; }
+          k.ref = n.child[c];
+          kids.push_back(k);
+        }
+      };
+      addKids(j.binNode);
+      while (kids.size() < 4) {
+        int best = -1;
+        double bestArea = -1;
+        for (size_t i = 0; i < kids.size(); i++)
+          if (kids[i].ref >= 0 && kids[i].box.area() > bestArea) { bestArea = kids[i].box.area(); best = (int)i; }
+        if (best < 0) break;
+        const int b = kids[best].ref;
+        kids.erase(kids.begin() + best);
+        addKids(b);
+      }
+      Node4 out;
+      std::memset(&out, 0, sizeof out);
+      Box all; all.reset();
+      for (const Kid& k : kids) all.grow(k.box);
+      for (int a = 0; a < 3; a++) {
+        out.origin[a] = down(all.lo[a]);
+        const double ext = all.hi[a] - (double)out.origin[a];
+        int e = -126;
+        if (ext > 0) {
+          e = (int)std::ceil(std::log2(ext / 255.0));
+          while (std::ldexp(255.0, e) < ext) e++;   // guard the rounding of log2
+          e = std::max(-126, std::min(127, e));
+        }
+        out.exp[a] = (int8_t)e;
+      }
+      for (int c = 0; c < 4; c++) {
+        if (c >= (int)kids.size()) {
+          out.child[c] = kEmptyChild;
+          for (int a = 0; a < 3; a++) { out.qlo[c][a] = 255; out.qhi[c][a] = 0; }
+          continue;
+        }
+        const Kid& k = kids[c];
+        for (int a = 0; a < 3; a++) {
+          const double sc = std::ldexp(1.0, out.exp[a]);
+          double ql = std::floor((k.box.lo[a] - (double)out.origin[a]) / sc);
+          double qh = std::ceil((k.box.hi[a] - (double)out.origin[a]) / sc);
+          ql = std::min(255.0, std::max(0.0, ql));
+          qh = std::min(255.0, std::max(0.0, qh));
+          out.qlo[c][a] = (uint8_t)ql;
+          out.qhi[c][a] = (uint8_t)qh;
+        }
+        if (k.ref >= 0) {
+          const int idx = (int)nodes.size();
+          nodes.emplace_back();
+          out.child[c] = idx;
+          jobs.push_back({k.ref, idx, j.depth + 1});
+        } else {
+          out.child[c] = k.ref;
+        }
+      }
+      nodes[j.out] = out;
+    }
+  }
+
+ private:
+  const std::vector<Node>* bin_ = nullptr;
 };
 
 }  // namespace rtbvh

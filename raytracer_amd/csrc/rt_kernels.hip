@@ -32,6 +32,7 @@
 #include <cstring>
 #include <memory>
 #include <string>
+#include <limits>
 #include <vector>
 
 #include "../../include/rt_amd.h"
@@ -685,6 +686,11 @@ struct RtScene {
   Pool pool;
   std::vector<void*> poolAllocs;
   size_t poolLights = 0;
+  // pool slots one sample is expected to need (rays or shade points over all
+  // recursion levels); measured by the batches rendered so far at growthDepth
+  double growth = 6.0;
+  bool growthMeasured = false;
+  int growthDepth = -1;
   unsigned char* frameRgb = nullptr; int* frameHit = nullptr; size_t framePixels = 0;
   long long* tileOffsets = nullptr; size_t tileOffsetsCap = 0;
   double* jitterDev = nullptr; size_t jitterCap = 0;
@@ -825,6 +831,7 @@ struct RenderCtx {
   const long long* tileOffDev;
   RtStats stats;
   bool fast, wantStats;
+  double growthSeen = 0.0;
 };
 
 template <bool FAST, bool STATS>
@@ -856,7 +863,7 @@ void timedEnd(RtScene* sc) {
 
 // Renders pixel slots [first, first+count) of the frame map.  Returns
 // RT_OK, an error, or +1 when the ray pool overflowed (caller splits the batch).
-int renderBatch(RenderCtx& cx, long long first, int count) {
+int renderBatch(RenderCtx& cx, long long first, int count, long long* slotsUsed) {
   RtScene* sc = cx.sc;
   Pool& P = sc->pool;
   const RtRenderParams& rp = *cx.rp;
@@ -921,32 +928,61 @@ int renderBatch(RenderCtx& cx, long long first, int count) {
   cx.stats.prims_tested += prims;
   for (const LevelInfo& L : levels) cx.stats.shade_points += (unsigned long long)L.nsp;
   cx.stats.batches++;
+  *slotsUsed = (long long)std::max(rayOff, spOff);
   return RT_OK;
 }
 
-int renderRange(RenderCtx& cx, long long first, long long count, long long batch) {
-  for (long long b = first; b < first + count; b += batch) {
-    const int c = (int)std::min(batch, first + count - b);
-    int rc = renderBatch(cx, b, c);
+// Pixel slots per batch such that the expected number of pool slots
+// (samples x growth) fits the pool.
+long long batchFor(const RenderCtx& cx) {
+  const RtScene* sc = cx.sc;
+  const int ns = cx.fm.ns;
+  long long b = (long long)((double)sc->pool.cap / (sc->growth * ns));
+  if (cx.rp->max_batch_samples > 0) b = std::min<long long>(b, cx.rp->max_batch_samples / ns);
+  return std::max<long long>(64, b / 64 * 64);
+}
+
+// Renders pixel slots [first, first+count) in batches.  The batch size follows
+// the growth (pool slots per sample) that the batches before it really had:
+// deep recursion levels hold few rays but each costs the latency of its longest
+// ray, so few large batches beat many small ones.
+int renderRange(RenderCtx& cx, long long first, long long count) {
+  RtScene* sc = cx.sc;
+  const long long end = first + count;
+  long long limit = std::numeric_limits<long long>::max();
+  long long b = first;
+  while (b < end) {
+    const int c = (int)std::min(std::min(batchFor(cx), limit), end - b);
+    long long used = 0;
+    int rc = renderBatch(cx, b, c, &used);
     if (rc == 1) {
       if (c <= 64) return fail(RT_ERR_NOMEM, "ray pool too small for a 64-pixel batch");
-      HIP_TRY(hipStreamSynchronize(cx.sc->stream));
-      rc = renderRange(cx, b, c, std::max<long long>(64, (c / 2 + 63) / 64 * 64));
+      HIP_TRY(hipStreamSynchronize(sc->stream));
+      limit = std::max<long long>(64, (c / 2 + 63) / 64 * 64);
+      sc->growth = std::max(sc->growth, 1.5 * (double)sc->pool.cap / ((double)c * cx.fm.ns));
+      continue;
     }
     if (rc != RT_OK) return rc;
+    const double seen = 1.15 * (double)used / ((double)c * cx.fm.ns) + 0.05;
+    if (!sc->growthMeasured) { sc->growth = seen; sc->growthMeasured = true; }
+    else sc->growth = std::max(sc->growth, seen);
+    cx.growthSeen = std::max(cx.growthSeen, seen);
+    b += c;
   }
   return RT_OK;
 }
 
-size_t workspaceBudgetBytes() {
-  size_t mb = 12288;
+// Bytes the ray pool may take: half of the free device memory up to 64 GiB
+// (RT_AMD_WORKSPACE_MB overrides the ceiling).
+size_t workspaceBudgetBytes(size_t alreadyHeld) {
+  size_t mb = 65536;
   if (const char* e = std::getenv("RT_AMD_WORKSPACE_MB")) {
     long v = std::atol(e);
     if (v >= 64) mb = (size_t)v;
   }
   size_t freeB = 0, totalB = 0;
   if (hipMemGetInfo(&freeB, &totalB) == hipSuccess && freeB > 0)
-    mb = std::min(mb, (freeB / (1024 * 1024)) * 3 / 4);
+    mb = std::min(mb, ((freeB + alreadyHeld) / (1024 * 1024)) / 2);
   return mb * 1024 * 1024;
 }
 
@@ -1127,18 +1163,27 @@ int rt_scene_create(const RtSceneDesc* d, RtScene** out) {
       }
     }
     rtbvh::Builder bvh;
+    rtbvh::Collapser wide;
     D.bvh_valid = bvh.build(prims) ? 1 : 0;
     if (D.bvh_valid) {
-      if (bvh.maxDepth + 2 > RT_BVH_STACK) return fail(RT_ERR_UNSUPPORTED, "BVH deeper than the traversal stack allows");
+      wide.run(bvh.nodes);
+      if (3 * wide.maxDepth + 2 > RT_BVH_STACK) {
+        // pathological SAH depth: rebuild with median splits (depth <= log2 n + 1)
+        bvh.balanced = true;
+        bvh.build(prims);
+        wide.run(bvh.nodes);
+        if (3 * wide.maxDepth + 2 > RT_BVH_STACK)
+          return fail(RT_ERR_UNSUPPORTED, "BVH deeper than the traversal stack allows");
+      }
       std::vector<DevTri> ordered(bvh.triOrder.size());
       for (size_t i = 0; i < ordered.size(); i++) {
         if (bvh.triOrder[i] & rtbvh::kObjectBit) std::memset(&ordered[i], 0, sizeof(DevTri));
         else ordered[i] = tris[bvh.triOrder[i]];
       }
       DevTri* bt; HIP_TRY(upload(ordered.data(), ordered.size(), &bt)); keep(bt); D.bvhTris = bt;
-      static_assert(sizeof(rtbvh::Node) == sizeof(DevBvhNode), "BVH node layouts differ");
+      static_assert(sizeof(rtbvh::Node4) == sizeof(DevBvhNode), "BVH node layouts differ");
       DevBvhNode* bn;
-      HIP_TRY(upload(reinterpret_cast<const DevBvhNode*>(bvh.nodes.data()), bvh.nodes.size(), &bn));
+      HIP_TRY(upload(reinterpret_cast<const DevBvhNode*>(wide.nodes.data()), wide.nodes.size(), &bn));
       keep(bn);
       D.bvh = bn;
       for (int a = 0; a < 3; a++) {
@@ -1225,10 +1270,16 @@ int rt_render(RtScene* sc, const RtRenderParams* rp, unsigned char* rgb8_out, in
 
   // ---- workspace
   {
+    if (sc->growthDepth != rp->depth) {
+      // a chain of rays per bounce, a tree where surfaces also refract
+      sc->growth = (double)std::min<long long>((1ll << std::min(rp->depth + 1, 20)) - 1, 6);
+      sc->growthMeasured = false;
+      sc->growthDepth = rp->depth;
+    }
     const size_t perSlot = poolBytesPerSlot(sc->nLights);
-    size_t cap = workspaceBudgetBytes() / perSlot;
+    size_t cap = workspaceBudgetBytes(sc->pool.cap * poolBytesPerSlot((int)sc->poolLights)) / perSlot;
     const long long slots = (long long)TL.nTiles * rp->tile_w * rp->tile_h * nsFull;
-    const size_t want = (size_t)std::max<long long>(slots * 8, 1 << 16);
+    const size_t want = (size_t)std::max<double>((double)slots * sc->growth * 1.1, 1 << 16);
     cap = std::min(cap, want);
     cap = std::min<size_t>(cap, 0x3fffffff);
     if (rp->max_batch_samples > 0) cap = std::min<size_t>(cap, (size_t)rp->max_batch_samples * 8);
@@ -1290,15 +1341,7 @@ int rt_render(RtScene* sc, const RtRenderParams* rp, unsigned char* rgb8_out, in
   sc->eventsUsed = 0;
   HIP_TRY(hipEventRecord(sc->evStart, sc->stream));
   const long long pixelSlots = (long long)TL.nTiles * rp->tile_w * rp->tile_h;
-  auto batchFor = [&](int ns) {
-    // expected growth of a sample into pool slots: a chain per bounce, bounded
-    const long long growth = std::min<long long>((1ll << std::min(rp->depth + 1, 20)) - 1, 6);
-    long long b = (long long)sc->pool.cap / (growth * ns);
-    if (rp->max_batch_samples > 0) b = std::min<long long>(b, rp->max_batch_samples / ns);
-    b = std::max<long long>(64, b / 64 * 64);
-    return b;
-  };
-  int rc = renderRange(cx, 0, pixelSlots, batchFor(fm.ns));
+  int rc = renderRange(cx, 0, pixelSlots);
   if (rc != RT_OK) return rc;
   cx.stats.rays_primary = (unsigned long long)TL.pixels * fm.ns;
 
@@ -1326,7 +1369,7 @@ int rt_render(RtScene* sc, const RtRenderParams* rp, unsigned char* rgb8_out, in
       int* keepHit = cx.hitDev;
       cx.hitDev = nullptr;  // the base pass already recorded the primary hits
       const long long nFlag = (long long)flagged.size() / 2;
-      rc = renderRange(cx, 0, nFlag, batchFor(fm.ns));
+      rc = renderRange(cx, 0, nFlag);
       cx.hitDev = keepHit;
       cx.stats.rays_primary += (unsigned long long)nFlag * nsFull;
       if (rc != RT_OK) { hipFree(listDev); return rc; }
@@ -1362,6 +1405,7 @@ int rt_render(RtScene* sc, const RtRenderParams* rp, unsigned char* rgb8_out, in
     HIP_TRY(hipStreamSynchronize(sc->stream));
   }
   if (listDev) hipFree(listDev);
+  if (cx.growthSeen > 0.0) sc->growth = cx.growthSeen;
 
   float ms = 0.f;
   HIP_TRY(hipEventElapsedTime(&ms, sc->evStart, sc->evStop));

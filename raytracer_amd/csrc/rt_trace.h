@@ -44,13 +44,18 @@ struct DevTri {
   int face;       // global face index (position in the caller's faces[] array)
 };
 
-// 64-byte BVH node, see rt_bvh.h for the child encoding.
+// 64-byte 4-wide BVH node with 8-bit quantised child boxes, see rt_bvh.h.
 struct DevBvhNode {
-  float lo[2][3], hi[2][3];
-  int child[2];
-  int pad[2];
+  float origin[3];
+  int8_t exp[3];
+  uint8_t pad0;
+  int child[4];
+  uint8_t qlo[4][3];
+  uint8_t qhi[4][3];
+  uint8_t pad1[8];
 };
 #define RT_BVH_OBJECT_BIT 0x40000000
+#define RT_BVH_EMPTY 0x7fffffff
 
 struct DevScene {
   const DevNode* nodes;
@@ -512,7 +517,7 @@ __device__ int traceKdReference(const DevScene& S, const V3& p, const V3& d, int
 }
 
 // -------------------------------------------------------------- BVH traversal
-#define RT_BVH_STACK 64
+#define RT_BVH_STACK 96
 
 struct BvhEntry { int ref; float tn; };
 
@@ -521,18 +526,9 @@ __device__ __forceinline__ float roundDownF(double x) {
   return ((double)f > x) ? nextafterf(f, -INFINITY) : f;
 }
 
-// Slab test of one child box (float, rounded outward at build time) in double
-// arithmetic.  fmin/fmax drop the NaN of 0 * inf when the origin lies on a slab
-// plane of an axis the ray is parallel to.
-__device__ __forceinline__ bool bvhChildHit(const DevBvhNode& n, int c, const V3& p, const V3& inv,
-                                            double tMaxCull, double& tn) {
-  const double x0 = ((double)n.lo[c][0] - p.x) * inv.x, x1 = ((double)n.hi[c][0] - p.x) * inv.x;
-  const double y0 = ((double)n.lo[c][1] - p.y) * inv.y, y1 = ((double)n.hi[c][1] - p.y) * inv.y;
-  const double z0 = ((double)n.lo[c][2] - p.z) * inv.z, z1 = ((double)n.hi[c][2] - p.z) * inv.z;
-  const double tnear = fmax(fmax(fmin(x0, x1), fmin(y0, y1)), fmax(fmin(z0, z1), 0.0));
-  const double tfar = fmin(fmin(fmax(x0, x1), fmax(y0, y1)), fmin(fmax(z0, z1), tMaxCull));
-  tn = tnear;
-  return tnear <= tfar * 1.000000000001;
+// 2^e as a double, e in [-126, 127]
+__device__ __forceinline__ double pow2i(int e) {
+  return __longlong_as_double((long long)(e + 1023) << 52);
 }
 
 // Closest hit (ANYHIT false) or occlusion query (ANYHIT true) on the library's
@@ -568,21 +564,43 @@ __device__ int traceBvh(const DevScene& S, const V3& p, const V3& d, int rayType
     if (ref >= 0) {
       const DevBvhNode n = S.bvh[ref];
       if (STATS) cnt.nodes++;
-      double tn0, tn1;
-      const bool h0 = bvhChildHit(n, 0, p, inv, bestT, tn0);
-      const bool h1 = bvhChildHit(n, 1, p, inv, bestT, tn1) && n.child[1] != n.child[0];
-      if (h0 && h1) {
-        const bool firstIs0 = tn0 <= tn1;
-        if (sp < RT_BVH_STACK) {
-          stack[sp].ref = firstIs0 ? n.child[1] : n.child[0];
-          stack[sp].tn = roundDownF(firstIs0 ? tn1 : tn0);
-          sp++;
-        }
-        ref = firstIs0 ? n.child[0] : n.child[1];
+      // slab planes of child c on axis a: origin + q * 2^exp; with
+      // A = (origin - p) * inv and B = 2^exp * inv the plane distance is A + q*B
+      const double sx = pow2i(n.exp[0]) * inv.x, sy = pow2i(n.exp[1]) * inv.y, sz = pow2i(n.exp[2]) * inv.z;
+      const double ax = ((double)n.origin[0] - p.x) * inv.x, ay = ((double)n.origin[1] - p.y) * inv.y,
+                   az = ((double)n.origin[2] - p.z) * inv.z;
+      // distances of the four children (+inf when missed), kept in registers:
+      // every index below is a compile-time constant after unrolling
+      double tn[4];
+      int kid[4];
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        const double x0 = ax + (double)n.qlo[c][0] * sx, x1 = ax + (double)n.qhi[c][0] * sx;
+        const double y0 = ay + (double)n.qlo[c][1] * sy, y1 = ay + (double)n.qhi[c][1] * sy;
+        const double z0 = az + (double)n.qlo[c][2] * sz, z1 = az + (double)n.qhi[c][2] * sz;
+        // fmin/fmax drop the NaN of 0 * inf (origin on a slab plane of an axis the ray is parallel to)
+        const double tnear = fmax(fmax(fmin(x0, x1), fmin(y0, y1)), fmax(fmin(z0, z1), 0.0));
+        const double tfar = fmin(fmin(fmax(x0, x1), fmax(y0, y1)), fmin(fmax(z0, z1), bestT));
+        const bool hit = n.child[c] != RT_BVH_EMPTY && tnear <= tfar * 1.000000000001 + 1e-12;
+        tn[c] = hit ? tnear : __longlong_as_double(0x7ff0000000000000LL);
+        kid[c] = n.child[c];
+      }
+      // ascending sorting network on (tn, kid): (0,1)(2,3)(0,2)(1,3)(1,2)
+#define RT_CSWAP(i, j)                                                       \
+      if (tn[j] < tn[i]) {                                                   \
+        const double tt = tn[i]; tn[i] = tn[j]; tn[j] = tt;                  \
+        const int kk = kid[i]; kid[i] = kid[j]; kid[j] = kk;                 \
+      }
+      RT_CSWAP(0, 1) RT_CSWAP(2, 3) RT_CSWAP(0, 2) RT_CSWAP(1, 3) RT_CSWAP(1, 2)
+#undef RT_CSWAP
+      if (tn[0] < 1.0e308) {
+        // farthest first onto the stack, the nearest child is visited next
+        if (tn[3] < 1.0e308 && sp < RT_BVH_STACK) { stack[sp].ref = kid[3]; stack[sp].tn = roundDownF(tn[3]); sp++; }
+        if (tn[2] < 1.0e308 && sp < RT_BVH_STACK) { stack[sp].ref = kid[2]; stack[sp].tn = roundDownF(tn[2]); sp++; }
+        if (tn[1] < 1.0e308 && sp < RT_BVH_STACK) { stack[sp].ref = kid[1]; stack[sp].tn = roundDownF(tn[1]); sp++; }
+        ref = kid[0];
         continue;
       }
-      if (h0) { ref = n.child[0]; continue; }
-      if (h1) { ref = n.child[1]; continue; }
     } else {
       const int x = ~ref;
       if (x & RT_BVH_OBJECT_BIT) {
