@@ -60,15 +60,26 @@ struct Pool {
   double* rayP[2]; double* rayD[2]; int* rayType[2];
   double* hitT; int* hitPrim;
   // shade points of the current level (indexed 0..nsp)
-  double* spQ; double* spN; double* spKd; double* spKs; double* spShin; int* spLit; int* spRayLocal;
+  double* spQ; double* spN;
   double* lightD; double* lightS;                // [n_lights][3][cap]
   // persistent for the whole batch (pool slot / pool shade-point index)
   double* rayI;
-  double* spShade; double* spKr; double* spKt; double* spIor;
+  double* spShade;
+  int* spMat;                                    // RT_SPM_* word: material index, lit flag
   int* spChildRefl; int* spChildRefr; int* spRayGlobal;
+  // only for shade points whose material is interpolated from vertex materials
+  // (RT_SPM_INTERP); one-element stubs when the scene has none
+  double* spKd; double* spKs; double* spShin;    // by level index
+  double* spKr; double* spKt; double* spIor;     // by pool index
   int* primaryId;                                // objectID of the level-0 hit per sample
   Counters* counters;
 };
+
+// Shade-point material word: index into DevScene::devMats, or RT_SPM_INTERP when
+// the material was interpolated and lives in the per-point arrays.
+#define RT_SPM_INTERP 0x80000000u
+#define RT_SPM_LIT 0x40000000u                   // kd or ks non-zero: lights contribute
+#define RT_SPM_INDEX 0x3fffffffu
 
 struct FrameMap {           // pixel slot -> pixel, for tile-ordered rendering
   int width, height;
@@ -267,27 +278,37 @@ k_surface(DevScene S, int n, int items, int par, size_t rayOff, size_t spOff, in
     const int prim = P.hitPrim[i];
     const V3 p = loadV3(P.rayP[par], P.cap, i), d = loadV3(P.rayD[par], P.cap, i);
     const double t = P.hitT[i];
+    const size_t g = spOff + s;
     Surface sf;
-    MatD m;
-    surfaceAt(S, prim, p, d, type, sf, &m, false);
+    bool lit;
+    int tableMat = -1;
+    if (prim & RT_PRIM_FACE) {
+      const RtObject& o = S.objects[S.tris[prim & ~RT_PRIM_FACE].owner];
+      if (!(S.smooth && S.meshes[o.mesh].has_vertex_materials)) tableMat = o.material;
+    } else {
+      tableMat = S.objects[prim].material;
+    }
+    if (tableMat >= 0) {
+      surfaceAt(S, prim, p, d, type, sf, nullptr, false);
+      lit = (S.devMats[tableMat].flags & (RT_MATF_KD | RT_MATF_KS)) != 0;   // material.cpp:50-53
+      P.spMat[g] = (int)((unsigned int)tableMat | (lit ? RT_SPM_LIT : 0u));
+    } else {
+      MatD m;
+      surfaceAt(S, prim, p, d, type, sf, &m, false);
+      lit = !(iszero(m.kd) && iszero(m.ks));
+      P.spMat[g] = (int)(RT_SPM_INTERP | (lit ? RT_SPM_LIT : 0u));
+      storeV3(P.spKd, P.cap, s, m.kd);
+      storeV3(P.spKs, P.cap, s, m.ks);
+      P.spShin[s] = shininessOf(m);
+      storeV3(P.spShade, P.cap, g, m.ke + prod(m.ka, V3(S.ambient)));   // material.cpp:46
+      storeV3(P.spKr, P.cap, g, m.kr);
+      storeV3(P.spKt, P.cap, g, m.kt);
+      P.spIor[g] = intensityValue(m.index);                              // Material::index (material.h:217)
+    }
     if (level == 0) P.primaryId[i] = sf.objectID;
-    const V3 Q = p + (t * d);                                  // ray::at (ray.h:42-43)
-    const V3 base = m.ke + prod(m.ka, V3(S.ambient));          // material.cpp:46
-    const bool lit = !(iszero(m.kd) && iszero(m.ks));          // material.cpp:50-53
+    const V3 Q = p + (t * d);                                            // ray::at (ray.h:42-43)
     storeV3(P.spQ, P.cap, s, Q);
     storeV3(P.spN, P.cap, s, sf.N);
-    storeV3(P.spKd, P.cap, s, m.kd);
-    storeV3(P.spKs, P.cap, s, m.ks);
-    P.spShin[s] = shininessOf(m);
-    P.spLit[s] = lit ? 1 : 0;
-    P.spRayLocal[s] = i;
-    const size_t g = spOff + s;
-    storeV3(P.spShade, P.cap, g, base);
-    storeV3(P.spKr, P.cap, g, m.kr);
-    storeV3(P.spKt, P.cap, g, m.kt);
-    P.spIor[g] = intensityValue(m.index);                      // Material::index (material.h:217)
-    P.spChildRefl[g] = -1;
-    P.spChildRefr[g] = -1;
     P.spRayGlobal[g] = (int)(rayOff + i);
     if (lit) myLit++;
   }
@@ -300,14 +321,15 @@ k_surface(DevScene S, int n, int items, int par, size_t rayOff, size_t spOff, in
 // Material::shade for that light (material.cpp:54-73, light.cpp:14-149).
 template <bool FAST, bool STATS>
 __global__ void __launch_bounds__(kBlock)
-k_lights(DevScene S, long long nMax, Pool P) {
+k_lights(DevScene S, long long nMax, size_t spOff, Pool P) {
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const unsigned int nsp = P.counters->nsp;
   TraceCounters tc{0, 0};
   if (idx < nMax && idx < (long long)nsp * S.n_lights) {
     const int li = (int)(idx / nsp);
     const int s = (int)(idx % nsp);
-    if (P.spLit[s]) {
+    const unsigned int mw = (unsigned int)P.spMat[spOff + s];
+    if (mw & RT_SPM_LIT) {
       const RtLight& l = S.lights[li];
       const V3 Q = loadV3(P.spQ, P.cap, s), N = loadV3(P.spN, P.cap, s);
       const V3 color(l.color);
@@ -380,19 +402,31 @@ k_lights(DevScene S, long long nMax, Pool P) {
         }
       }
       const V3 lightIntensity = distanceAttenuation(l, Q) * atten;
-      const V3 kd = loadV3(P.spKd, P.cap, s), ks = loadV3(P.spKs, P.cap, s);
+      V3 kd, ks;
+      double shin;
+      if (mw & RT_SPM_INTERP) {
+        kd = loadV3(P.spKd, P.cap, s);
+        ks = loadV3(P.spKs, P.cap, s);
+        shin = P.spShin[s];
+      } else {
+        const DevMat& dm = S.devMats[mw & RT_SPM_INDEX];
+        kd = V3(dm.kd);
+        ks = V3(dm.ks);
+        shin = dm.shin;
+      }
       const V3 D = prod(kd, lightIntensity) * fmax(dot(N, L), 0.0);
       V3 Sp(0, 0, 0);
-      if (!iszero(ks)) {
+      const bool hasKs = !iszero(ks);
+      if (hasKs) {
         const V3 view = normalized(V3(S.eye) - Q);             // material.cpp:66-67
         const V3 cosVector = N * dot(L, N);
         const V3 sinVector = cosVector - L;
         const V3 refl = normalized(cosVector + sinVector);
-        Sp = prod(ks, lightIntensity) * pow(fmax(dot(refl, view), 0.0), P.spShin[s]);
+        Sp = prod(ks, lightIntensity) * pow(fmax(dot(refl, view), 0.0), shin);
       }
       const size_t o = (size_t)li * 3 * P.cap;
-      storeV3(P.lightD + o, P.cap, s, D);
-      storeV3(P.lightS + o, P.cap, s, Sp);
+      if (!iszero(kd)) storeV3(P.lightD + o, P.cap, s, D);   // k_shade reads what it adds only
+      if (hasKs) storeV3(P.lightS + o, P.cap, s, Sp);
     }
   }
   if (STATS) flushCounters(tc, P.counters);
@@ -402,7 +436,8 @@ k_lights(DevScene S, long long nMax, Pool P) {
 // RayTracer::traceRay (RayTracer.cpp:152-201).  Reflected rays of a tile are
 // queued before its refracted rays.
 __global__ void __launch_bounds__(kBlock)
-k_shade(DevScene S, int nMax, int items, int par, size_t spOff, size_t nextRayOff, int depthLeft, Pool P) {
+k_shade(DevScene S, int nMax, int items, int par, size_t spOff, size_t rayOff, size_t nextRayOff,
+        int depthLeft, Pool P) {
   __shared__ TileScan ts;
   const unsigned int nsp = min((unsigned int)nMax, P.counters->nsp);
   const int tileBase = blockIdx.x * kBlock * items;
@@ -414,23 +449,32 @@ k_shade(DevScene S, int nMax, int items, int par, size_t spOff, size_t nextRayOf
     bool wantRefl = false, wantRefr = false;
     if ((unsigned int)s < nsp) {
       const size_t g = spOff + s;
-      if (P.spLit[s]) {
-        V3 I = loadV3(P.spShade, P.cap, g);
-        const bool hasKd = !iszero(loadV3(P.spKd, P.cap, s)), hasKs = !iszero(loadV3(P.spKs, P.cap, s));
+      const unsigned int mw = (unsigned int)P.spMat[g];
+      const bool interp = (mw & RT_SPM_INTERP) != 0;
+      const DevMat* dm = interp ? nullptr : &S.devMats[mw & RT_SPM_INDEX];
+      if (mw & RT_SPM_LIT) {
+        V3 I = interp ? loadV3(P.spShade, P.cap, g) : V3(dm->base);
+        const bool hasKd = interp ? !iszero(loadV3(P.spKd, P.cap, s)) : (dm->flags & RT_MATF_KD) != 0;
+        const bool hasKs = interp ? !iszero(loadV3(P.spKs, P.cap, s)) : (dm->flags & RT_MATF_KS) != 0;
         for (int li = 0; li < S.n_lights; li++) {
           const size_t o = (size_t)li * 3 * P.cap;
           if (hasKd) I = I + loadV3(P.lightD + o, P.cap, s);
           if (hasKs) I = I + loadV3(P.lightS + o, P.cap, s);
         }
         storeV3(P.spShade, P.cap, g, I);
+      } else if (!interp) {
+        storeV3(P.spShade, P.cap, g, V3(dm->base));
       }
       if (depthLeft > 0) {
-        wantRefl = !iszero(loadV3(P.spKr, P.cap, g));
-        if (!iszero(loadV3(P.spKt, P.cap, g))) {
-          const V3 d = loadV3(P.rayD[par], P.cap, P.spRayLocal[s]);
+        wantRefl = interp ? !iszero(loadV3(P.spKr, P.cap, g)) : (dm->flags & RT_MATF_KR) != 0;
+        if (interp ? !iszero(loadV3(P.spKt, P.cap, g)) : (dm->flags & RT_MATF_KT) != 0) {
+          const V3 d = loadV3(P.rayD[par], P.cap, (size_t)P.spRayGlobal[g] - rayOff);
           const double cosineAngle = acos(dot(loadV3(P.spN, P.cap, s), d)) * 180 / M_PI;
           wantRefr = cosineAngle < 360;  // RayTracer.cpp:173,195: false only for a NaN angle
         }
+      } else {
+        P.spChildRefl[g] = -1;
+        P.spChildRefr[g] = -1;
       }
     }
     reflMask |= (wantRefl ? 1u : 0u) << k;
@@ -452,85 +496,120 @@ k_shade(DevScene S, int nMax, int items, int par, size_t spOff, size_t nextRayOf
     const bool wantRefl = (reflMask >> k) & 1u, wantRefr = (refrMask >> k) & 1u;
     const unsigned int a = tileSlot(ts, 0, k, wantRefl);
     const unsigned int b = tileSlot(ts, 1, k, wantRefr);
-    if (!(wantRefl || wantRefr)) continue;
+    if ((unsigned int)s >= nsp) continue;
     const size_t g = spOff + s;
-    const V3 d = loadV3(P.rayD[par], P.cap, P.spRayLocal[s]);
-    const V3 N = loadV3(P.spN, P.cap, s);
-    const V3 Q = loadV3(P.spQ, P.cap, s);
-    const V3 minusD = -1 * d;
-    const V3 cosVector = N * dot(minusD, N);
-    const V3 sinVector = cosVector + d;
-    if (wantRefl) {
-      if (nextRayOff + a >= P.cap) {
-        P.counters->overflow = 1;
-      } else {
-        const V3 reflDir = normalized(cosVector + sinVector);
-        storeV3(P.rayP[np], P.cap, a, Q);
-        storeV3(P.rayD[np], P.cap, a, reflDir);
-        P.rayType[np][a] = RT_RAY_REFLECTION;
-        P.spChildRefl[g] = (int)(nextRayOff + a);
+    int childRefl = -1, childRefr = -1;
+    if (wantRefl || wantRefr) {
+      const V3 d = loadV3(P.rayD[par], P.cap, (size_t)P.spRayGlobal[g] - rayOff);
+      const V3 N = loadV3(P.spN, P.cap, s);
+      const V3 Q = loadV3(P.spQ, P.cap, s);
+      const V3 minusD = -1 * d;
+      const V3 cosVector = N * dot(minusD, N);
+      const V3 sinVector = cosVector + d;
+      if (wantRefl) {
+        if (nextRayOff + a >= P.cap) {
+          P.counters->overflow = 1;
+        } else {
+          const V3 reflDir = normalized(cosVector + sinVector);
+          storeV3(P.rayP[np], P.cap, a, Q);
+          storeV3(P.rayD[np], P.cap, a, reflDir);
+          P.rayType[np][a] = RT_RAY_REFLECTION;
+          childRefl = (int)(nextRayOff + a);
+        }
+      }
+      if (wantRefr) {
+        if (nextRayOff + b >= P.cap) {
+          P.counters->overflow = 1;
+        } else {
+          const unsigned int mw = (unsigned int)P.spMat[g];
+          const double ior = (mw & RT_SPM_INTERP) ? P.spIor[g] : S.devMats[mw & RT_SPM_INDEX].ior;
+          const double cosineAngle = acos(dot(N, d)) * 180 / M_PI;
+          double n_i, n_r;
+          int iDirection;
+          if (cosineAngle > 90) { n_i = 1; n_r = ior; iDirection = 1; }
+          else { n_i = ior; n_r = 1; iDirection = -1; }
+          const V3 sinT = (n_i / n_r) * sinVector;
+          const V3 cosT = (-1 * N) * sqrt(1 - dot(sinT, sinT));
+          const V3 rd = normalized(cosT + (double)iDirection * sinT);
+          storeV3(P.rayP[np], P.cap, b, Q);
+          storeV3(P.rayD[np], P.cap, b, (double)iDirection * rd);
+          P.rayType[np][b] = RT_RAY_REFRACTION;
+          childRefr = (int)(nextRayOff + b);
+        }
       }
     }
-    if (wantRefr) {
-      if (nextRayOff + b >= P.cap) {
-        P.counters->overflow = 1;
-      } else {
-        const double cosineAngle = acos(dot(N, d)) * 180 / M_PI;
-        double n_i, n_r;
-        int iDirection;
-        if (cosineAngle > 90) { n_i = 1; n_r = P.spIor[g]; iDirection = 1; }
-        else { n_i = P.spIor[g]; n_r = 1; iDirection = -1; }
-        const V3 sinT = (n_i / n_r) * sinVector;
-        const V3 cosT = (-1 * N) * sqrt(1 - dot(sinT, sinT));
-        const V3 rd = normalized(cosT + (double)iDirection * sinT);
-        storeV3(P.rayP[np], P.cap, b, Q);
-        storeV3(P.rayD[np], P.cap, b, (double)iDirection * rd);
-        P.rayType[np][b] = RT_RAY_REFRACTION;
-        P.spChildRefr[g] = (int)(nextRayOff + b);
-      }
-    }
+    P.spChildRefl[g] = childRefl;
+    P.spChildRefr[g] = childRefr;
   }
 }
 
 // intensity = shade; += kr*traceRay(reflected); += kt*traceRay(refracted)
 __global__ void __launch_bounds__(kBlock)
-k_combine(size_t spOff, int nsp, Pool P) {
+k_combine(DevScene S, size_t spOff, int nsp, Pool P) {
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= nsp) return;
   const size_t g = spOff + s;
   V3 I = loadV3(P.spShade, P.cap, g);
   const int cr = P.spChildRefl[g], ct = P.spChildRefr[g];
-  if (cr >= 0) I = I + prod(loadV3(P.spKr, P.cap, g), loadV3(P.rayI, P.cap, (size_t)cr));
-  if (ct >= 0) I = I + prod(loadV3(P.spKt, P.cap, g), loadV3(P.rayI, P.cap, (size_t)ct));
+  if (cr >= 0 || ct >= 0) {
+    const unsigned int mw = (unsigned int)P.spMat[g];
+    const bool interp = (mw & RT_SPM_INTERP) != 0;
+    const DevMat* dm = interp ? nullptr : &S.devMats[mw & RT_SPM_INDEX];
+    if (cr >= 0) I = I + prod(interp ? loadV3(P.spKr, P.cap, g) : V3(dm->kr), loadV3(P.rayI, P.cap, (size_t)cr));
+    if (ct >= 0) I = I + prod(interp ? loadV3(P.spKt, P.cap, g) : V3(dm->kt), loadV3(P.rayI, P.cap, (size_t)ct));
+  }
   storeV3(P.rayI, P.cap, (size_t)P.spRayGlobal[g], I);
 }
 
 // RayTracer::trace's clamp, tracePixel / tracePixelAntiAlias's byte conversion
 // (RayTracer.cpp:41,58-60,94-101).  tileOffset: packed-buffer pixel offset of
 // each of this shard's tiles, or NULL for a full-frame destination.
+//
+// A block resolves `ppb` consecutive pixels: all threads read the block's
+// ppb * ns sample colours with coalesced loads, clamp them and park them in LDS
+// (row pitch odd, so the column walk below is free of bank conflicts); then
+// one thread per pixel adds its ns samples in sample order, as the reference's
+// loop does.
+constexpr int kResolveSamples = 2048;   // LDS rows * pitch per colour channel
+
 __global__ void __launch_bounds__(kBlock)
-k_resolve(FrameMap fm, long long firstPixelSlot, int nPixels, Pool P, unsigned char* rgb, int* hitId,
-          const long long* tileOffset, const int* listIndex) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= nPixels) return;
-  const long long slot = firstPixelSlot + i;
-  int px, py, tk, lx, ly;
-  if (!slotToPixel(fm, slot, px, py, tk, lx, ly)) return;
-  V3 col(0, 0, 0);
-  for (int k = 0; k < fm.ns; k++) {
-    V3 c = loadV3(P.rayI, P.cap, (size_t)i * fm.ns + k);
+k_resolve(FrameMap fm, long long firstPixelSlot, int nPixels, int ppb, Pool P, unsigned char* rgb, int* hitId,
+          const long long* tileOffset) {
+  __shared__ double lds[3][kResolveSamples + kBlock];
+  __shared__ int ldsId[kBlock];
+  const int ns = fm.ns, pitch = ns | 1;
+  const int pix0 = blockIdx.x * ppb;
+  const int npix = min(ppb, nPixels - pix0);
+  const size_t base = (size_t)pix0 * ns;
+  for (int e = threadIdx.x; e < npix * ns; e += kBlock) {
+    V3 c = loadV3(P.rayI, P.cap, base + e);
     if (c.x < 0) c.x = 0.0;
     if (c.x > 1) c.x = 1.0;
     if (c.y < 0) c.y = 0.0;
     if (c.y > 1) c.y = 1.0;
     if (c.z < 0) c.z = 0.0;
     if (c.z > 1) c.z = 1.0;
-    if (fm.aaN > 0) col = V3(col.x + c.x, col.y + c.y, col.z + c.z);
-    else col = c;
+    const int pl = e / ns, k = e - pl * ns;
+    const int o = pl * pitch + k;
+    lds[0][o] = c.x;
+    lds[1][o] = c.y;
+    lds[2][o] = c.z;
+    if (k == 0 && hitId) ldsId[pl] = P.primaryId[base + e];
   }
+  __syncthreads();
+  const int pl = threadIdx.x;
+  if (pl >= npix) return;
+  const long long slot = firstPixelSlot + pix0 + pl;
+  int px, py, tk, lx, ly;
+  if (!slotToPixel(fm, slot, px, py, tk, lx, ly)) return;
+  V3 col(0, 0, 0);
+  const int r = pl * pitch;
   if (fm.aaN > 0) {
+    for (int k = 0; k < ns; k++) col = V3(col.x + lds[0][r + k], col.y + lds[1][r + k], col.z + lds[2][r + k]);
     const double nn = double(fm.aaN * fm.aaN);
     col = V3(col.x / nn, col.y / nn, col.z / nn);
+  } else {
+    col = V3(lds[0][r + ns - 1], lds[1][r + ns - 1], lds[2][r + ns - 1]);
   }
   size_t o;
   if (tileOffset) {
@@ -541,13 +620,12 @@ k_resolve(FrameMap fm, long long firstPixelSlot, int nPixels, Pool P, unsigned c
   } else {
     o = (size_t)px + (size_t)py * fm.width;
   }
-  (void)listIndex;
   // (int)(255.0*c) then narrowing to a byte; a NaN converts to 0 here and to
   // INT_MIN -> byte 0 on the reference's x86-64
   rgb[3 * o + 0] = (unsigned char)(int)(255.0 * col.x);
   rgb[3 * o + 1] = (unsigned char)(int)(255.0 * col.y);
   rgb[3 * o + 2] = (unsigned char)(int)(255.0 * col.z);
-  if (hitId) hitId[o] = P.primaryId[(size_t)i * fm.ns];
+  if (hitId) hitId[o] = ldsId[pl];
 }
 
 // Scene::intersect seam for tests: full isect of n rays.
@@ -761,6 +839,8 @@ int ensurePool(RtScene* sc, size_t cap) {
     if (e == hipSuccess) sc->poolAllocs.push_back(*out);
     return e;
   };
+  // per-point material arrays only where some mesh interpolates materials
+  const size_t icap = sc->dev.interp_materials ? cap : 1;
 #define POOL_ALLOC(field, type, count) HIP_TRY(A(sizeof(type) * (count), (void**)&(field)))
   for (int b = 0; b < 2; b++) {
     POOL_ALLOC(P.rayP[b], double, 3 * cap);
@@ -771,22 +851,21 @@ int ensurePool(RtScene* sc, size_t cap) {
   POOL_ALLOC(P.hitPrim, int, cap);
   POOL_ALLOC(P.spQ, double, 3 * cap);
   POOL_ALLOC(P.spN, double, 3 * cap);
-  POOL_ALLOC(P.spKd, double, 3 * cap);
-  POOL_ALLOC(P.spKs, double, 3 * cap);
-  POOL_ALLOC(P.spShin, double, cap);
-  POOL_ALLOC(P.spLit, int, cap);
-  POOL_ALLOC(P.spRayLocal, int, cap);
   POOL_ALLOC(P.lightD, double, nl * 3 * cap);
   POOL_ALLOC(P.lightS, double, nl * 3 * cap);
   POOL_ALLOC(P.rayI, double, 3 * cap);
   POOL_ALLOC(P.spShade, double, 3 * cap);
-  POOL_ALLOC(P.spKr, double, 3 * cap);
-  POOL_ALLOC(P.spKt, double, 3 * cap);
-  POOL_ALLOC(P.spIor, double, cap);
+  POOL_ALLOC(P.spMat, int, cap);
   POOL_ALLOC(P.spChildRefl, int, cap);
   POOL_ALLOC(P.spChildRefr, int, cap);
   POOL_ALLOC(P.spRayGlobal, int, cap);
   POOL_ALLOC(P.primaryId, int, cap);
+  POOL_ALLOC(P.spKd, double, 3 * icap);
+  POOL_ALLOC(P.spKs, double, 3 * icap);
+  POOL_ALLOC(P.spShin, double, icap);
+  POOL_ALLOC(P.spKr, double, 3 * icap);
+  POOL_ALLOC(P.spKt, double, 3 * icap);
+  POOL_ALLOC(P.spIor, double, icap);
   POOL_ALLOC(P.counters, Counters, 1);
 #undef POOL_ALLOC
   P.cap = cap;
@@ -794,9 +873,9 @@ int ensurePool(RtScene* sc, size_t cap) {
   return RT_OK;
 }
 
-size_t poolBytesPerSlot(int nLights) {
+size_t poolBytesPerSlot(int nLights, bool interp) {
   const size_t nl = (size_t)std::max(1, nLights);
-  return 2 * (48 + 4) + 12 + 24 * 4 + 8 + 4 + 4 + nl * 48 + 24 * 4 + 8 + 4 * 4;
+  return 2 * (48 + 4) + 12 + 24 * 2 + nl * 48 + 24 * 2 + 4 * 5 + (interp ? 24 * 4 + 8 * 2 : 0);
 }
 
 struct TileLayout {
@@ -841,8 +920,8 @@ void launchTrace(RtScene* sc, int n, int par) {
       sc->dev, n, P.rayP[par], P.rayD[par], P.rayType[par], P.cap, P.hitT, P.hitPrim, P.counters);
 }
 template <bool FAST, bool STATS>
-void launchLights(RtScene* sc, long long nMax) {
-  k_lights<FAST, STATS><<<gridFor(nMax), kBlock, 0, sc->stream>>>(sc->dev, nMax, sc->pool);
+void launchLights(RtScene* sc, long long nMax, size_t spOff) {
+  k_lights<FAST, STATS><<<gridFor(nMax), kBlock, 0, sc->stream>>>(sc->dev, nMax, spOff, sc->pool);
 }
 
 bool timedBegin(RtScene* sc) {
@@ -891,12 +970,12 @@ int renderBatch(RenderCtx& cx, long long first, int count, long long* slotsUsed)
     const long long lightThreads = (long long)n * sc->dev.n_lights;
     if (lightThreads > 0) {
       const bool timed2 = timedBegin(sc);
-      if (cx.fast) { if (cx.wantStats) launchLights<true, true>(sc, lightThreads); else launchLights<true, false>(sc, lightThreads); }
-      else { if (cx.wantStats) launchLights<false, true>(sc, lightThreads); else launchLights<false, false>(sc, lightThreads); }
+      if (cx.fast) { if (cx.wantStats) launchLights<true, true>(sc, lightThreads, spOff); else launchLights<true, false>(sc, lightThreads, spOff); }
+      else { if (cx.wantStats) launchLights<false, true>(sc, lightThreads, spOff); else launchLights<false, false>(sc, lightThreads, spOff); }
       if (timed2) timedEnd(sc);
       cx.stats.trace_launches++;
     }
-    k_shade<<<tiles, kBlock, 0, sc->stream>>>(sc->dev, n, items, par, spOff, rayOff + n,
+    k_shade<<<tiles, kBlock, 0, sc->stream>>>(sc->dev, n, items, par, spOff, rayOff, rayOff + n,
                                               rp.depth - level, P);
     Counters c;
     HIP_TRY(hipMemcpyAsync(&c, P.counters, sizeof c, hipMemcpyDeviceToHost, sc->stream));
@@ -915,10 +994,14 @@ int renderBatch(RenderCtx& cx, long long first, int count, long long* slotsUsed)
   }
   for (int li = (int)levels.size() - 1; li >= 0; li--) {
     const LevelInfo& L = levels[li];
-    if (L.nsp > 0) k_combine<<<gridFor(L.nsp), kBlock, 0, sc->stream>>>(L.spOff, L.nsp, P);
+    if (L.nsp > 0) k_combine<<<gridFor(L.nsp), kBlock, 0, sc->stream>>>(sc->dev, L.spOff, L.nsp, P);
   }
-  k_resolve<<<gridFor(count), kBlock, 0, sc->stream>>>(cx.fm, first, count, P, cx.rgbDev, cx.hitDev,
-                                                       cx.tileOffDev, nullptr);
+  {
+    const int pitch = ns | 1;
+    const int ppb = std::max(1, std::min(kBlock, kResolveSamples / pitch));
+    k_resolve<<<(count + ppb - 1) / ppb, kBlock, 0, sc->stream>>>(cx.fm, first, count, ppb, P, cx.rgbDev,
+                                                                    cx.hitDev, cx.tileOffDev);
+  }
   HIP_TRY(hipGetLastError());
   // stats: dead (out-of-frame) slots are not rays
   cx.stats.rays_reflect += refl;
@@ -1196,6 +1279,33 @@ int rt_scene_create(const RtSceneDesc* d, RtScene** out) {
   { RtMesh* p; HIP_TRY(upload(d->meshes, (size_t)d->n_meshes, &p)); keep(p); D.meshes = p; }
   { RtMaterial* p; HIP_TRY(upload(d->materials, (size_t)d->n_materials, &p)); keep(p); D.materials = p; }
   { RtLight* p; HIP_TRY(upload(d->lights, (size_t)d->n_lights, &p)); keep(p); D.lights = p; }
+  {
+    std::vector<DevMat> dm((size_t)d->n_materials);
+    for (int m = 0; m < d->n_materials; m++) {
+      const RtMaterial& M = d->materials[m];
+      DevMat& o = dm[m];
+      std::memset(&o, 0, sizeof o);
+      auto nz = [](const double* v) { return !(v[0] == 0.0 && v[1] == 0.0 && v[2] == 0.0); };
+      for (int k = 0; k < 3; k++) {
+        o.kd[k] = M.kd[k]; o.ks[k] = M.ks[k]; o.kr[k] = M.kr[k]; o.kt[k] = M.kt[k];
+        const double amb = M.ka[k] * d->ambient[k];
+        o.base[k] = M.ke[k] + amb;
+      }
+      const double si = (0.299 * M.shininess[0]) + (0.587 * M.shininess[1]) + (0.114 * M.shininess[2]);
+      o.shin = M.shininess_mapped ? 128.0 * si : si;
+      o.ior = (0.299 * M.index[0]) + (0.587 * M.index[1]) + (0.114 * M.index[2]);
+      o.flags = (nz(M.kd) ? RT_MATF_KD : 0) | (nz(M.ks) ? RT_MATF_KS : 0) | (nz(M.kr) ? RT_MATF_KR : 0) |
+                (nz(M.kt) ? RT_MATF_KT : 0);
+    }
+    DevMat* p;
+    HIP_TRY(upload(dm.data(), dm.size(), &p));
+    keep(p);
+    D.devMats = p;
+  }
+  D.interp_materials = 0;
+  if (d->smooth_shading)
+    for (int m = 0; m < d->n_meshes; m++)
+      if (d->meshes[m].has_vertex_materials) D.interp_materials = 1;
   if (d->vnormals) { double* p; HIP_TRY(upload(d->vnormals, 3 * (size_t)d->n_vertices, &p)); keep(p); D.vnormals = p; }
   if (d->vmaterials) { int* p; HIP_TRY(upload(d->vmaterials, (size_t)d->n_vertices, &p)); keep(p); D.vmaterials = p; }
   D.cube_w = D.cube_h = 0;
@@ -1276,8 +1386,9 @@ int rt_render(RtScene* sc, const RtRenderParams* rp, unsigned char* rgb8_out, in
       sc->growthMeasured = false;
       sc->growthDepth = rp->depth;
     }
-    const size_t perSlot = poolBytesPerSlot(sc->nLights);
-    size_t cap = workspaceBudgetBytes(sc->pool.cap * poolBytesPerSlot((int)sc->poolLights)) / perSlot;
+    const bool interp = sc->dev.interp_materials != 0;
+    const size_t perSlot = poolBytesPerSlot(sc->nLights, interp);
+    size_t cap = workspaceBudgetBytes(sc->pool.cap * poolBytesPerSlot((int)sc->poolLights, interp)) / perSlot;
     const long long slots = (long long)TL.nTiles * rp->tile_w * rp->tile_h * nsFull;
     const size_t want = (size_t)std::max<double>((double)slots * sc->growth * 1.1, 1 << 16);
     cap = std::min(cap, want);

@@ -57,7 +57,24 @@ struct DevBvhNode {
 #define RT_BVH_OBJECT_BIT 0x40000000
 #define RT_BVH_EMPTY 0x7fffffff
 
+// What the shading kernels need of one (non-interpolated) material, derived
+// once at scene creation with the reference's own expressions.
+struct DevMat {
+  double kd[3], ks[3], kr[3], kt[3];
+  double base[3];   // ke + ka (*) ambient            (material.cpp:46)
+  double shin;      // Material::shininess            (material.h:209-215)
+  double ior;       // Material::index as a scalar    (material.h:217)
+  int flags;        // RT_MATF_*
+  int pad;
+};
+#define RT_MATF_KD 1   // kd != 0
+#define RT_MATF_KS 2
+#define RT_MATF_KR 4
+#define RT_MATF_KT 8
+
 struct DevScene {
+  const DevMat* devMats;     // one per material
+  int interp_materials;      // 1: some mesh interpolates per-vertex materials
   const DevNode* nodes;
   const int* items;
   const DevTri* tris;
