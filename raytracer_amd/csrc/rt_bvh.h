@@ -230,9 +230,9 @@ struct Node4 {
   int8_t exp[3];
   uint8_t pad0;
   int32_t child[4];
-  uint8_t qlo[4][3];
-  uint8_t qhi[4][3];
-  uint8_t pad1[8];
+  uint32_t qlo[3];   // byte c of qlo[a]: lower plane of child c on axis a
+  uint32_t qhi[3];
+  uint32_t pad1[2];
 };
 static_assert(sizeof(Node4) == 64, "BVH4 node must be 64 bytes");
 constexpr int32_t kEmptyChild = 0x7fffffff;
@@ -299,7 +299,7 @@ class Collapser {
       for (int c = 0; c < 4; c++) {
         if (c >= (int)kids.size()) {
           out.child[c] = kEmptyChild;
-          for (int a = 0; a < 3; a++) { out.qlo[c][a] = 255; out.qhi[c][a] = 0; }
+          for (int a = 0; a < 3; a++) out.qlo[a] |= 255u << (8 * c);   // inverted box: upper planes stay 0
           continue;
         }
         const Kid& k = kids[c];
@@ -309,8 +309,8 @@ class Collapser {
           double qh = std::ceil((k.box.hi[a] - (double)out.origin[a]) / sc);
           ql = std::min(255.0, std::max(0.0, ql));
           qh = std::min(255.0, std::max(0.0, qh));
-          out.qlo[c][a] = (uint8_t)ql;
-          out.qhi[c][a] = (uint8_t)qh;
+          out.qlo[a] |= (uint32_t)ql << (8 * c);
+          out.qhi[a] |= (uint32_t)qh << (8 * c);
         }
         if (k.ref >= 0) {
           const int idx = (int)nodes.size();

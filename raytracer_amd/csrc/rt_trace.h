@@ -45,14 +45,15 @@ struct DevTri {
 };
 
 // 64-byte 4-wide BVH node with 8-bit quantised child boxes, see rt_bvh.h.
+// Byte c of qlo[a] / qhi[a] is the lower / upper plane of child c on axis a.
 struct DevBvhNode {
   float origin[3];
   int8_t exp[3];
   uint8_t pad0;
   int child[4];
-  uint8_t qlo[4][3];
-  uint8_t qhi[4][3];
-  uint8_t pad1[8];
+  uint32_t qlo[3];
+  uint32_t qhi[3];
+  uint32_t pad1[2];
 };
 #define RT_BVH_OBJECT_BIT 0x40000000
 #define RT_BVH_EMPTY 0x7fffffff
@@ -542,10 +543,28 @@ __device__ __forceinline__ float roundDownF(double x) {
   float f = (float)x;
   return ((double)f > x) ? nextafterf(f, -INFINITY) : f;
 }
+// a float that is not below x (x > 0)
+__device__ __forceinline__ float roundUpF(double x) {
+  const float f = (float)x;
+  return fmaf(fabsf(f), 0x1p-23f, f) + 1.0e-37f;
+}
 
-// 2^e as a double, e in [-126, 127]
+// 2^e, e in [-126, 127]
 __device__ __forceinline__ double pow2i(int e) {
   return __longlong_as_double((long long)(e + 1023) << 52);
+}
+__device__ __forceinline__ float pow2f(int e) { return __int_as_float((e + 127) << 23); }
+
+typedef float rt_f2 __attribute__((ext_vector_type(2)));
+
+// Slab distances of two children at once: q * B + A on both lanes of a packed
+// fused multiply-add.
+__device__ __forceinline__ rt_f2 slab2(uint32_t q, int c, float B, float A) {
+  rt_f2 qf;
+  qf.x = (float)((q >> (8 * c)) & 255u);
+  qf.y = (float)((q >> (8 * c + 8)) & 255u);
+  const rt_f2 b = {B, B}, a = {A, A};
+  return __builtin_elementwise_fma(qf, b, a);
 }
 
 // Closest hit (ANYHIT false) or occlusion query (ANYHIT true) on the library's
@@ -554,17 +573,51 @@ __device__ __forceinline__ double pow2i(int e) {
 // satisfies the reference's occlusion test |(p + t d) - p|^2 < occDist2
 // (light.cpp:77-80,123-126; occDist2 < 0: any hit counts, light.cpp:21), else
 // RT_PRIM_NONE.
+//
+// The box tests only decide which subtrees are skipped, never a result, so they
+// run in binary32 with every plane distance widened by a bound of its rounding
+// error (entry distances are lower bounds, exit distances upper bounds).
 template <bool ANYHIT, bool STATS>
 __device__ int traceBvh(const DevScene& S, const V3& p, const V3& d, int rayType, double tLimit,
                         double occDist2, double& tOut, TraceCounters& cnt) {
   tOut = 0.0;
   if (!S.bvh_valid) return RT_PRIM_NONE;
+  if (anynan(d) || anynan(p)) {
+    // A refraction past the critical angle leaves a NaN direction
+    // (RayTracer.cpp:193-199).  No comparison on a NaN orders anything, so no
+    // box can be culled; the reference's scan over Scene::objects
+    // (scene.cpp:144-153) then accepts the first object whose tests all fall
+    // through, and no triangle (trimesh.cpp:91-208 ends in range checks).
+    bool have = false;
+    double bt = 0.0;
+    int bp = RT_PRIM_NONE;
+    for (int j = 0; j < S.n_objects; j++) {
+      const RtObject& o = S.objects[j];
+      if (o.kind == RT_OBJ_TRIMESH) continue;
+      double t;
+      V3 N;
+      if (STATS) cnt.prims++;
+      if (objectIntersect<false>(o, p, d, t, N) && (!have || t < bt)) { have = true; bt = t; bp = j; }
+    }
+    if (!ANYHIT) { tOut = bt; return bp; }
+    if (have) {
+      const V3 Qh = p + (bt * d);
+      if (occDist2 < 0.0 || length2(Qh - p) < occDist2) { tOut = bt; return 0; }
+    }
+    return RT_PRIM_NONE;
+  }
   {
     double t0, t1;
     if (!boxIntersect(S.bvh_bb_min, S.bvh_bb_max, p, d, t0, t1)) return RT_PRIM_NONE;
   }
   const bool cullBack = S.cull && rayType != RT_RAY_REFRACTION;
   const V3 inv(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
+  // a direction component this small leaves the slab arithmetic; its axis gets
+  // an inside / outside test of the origin instead (see below)
+  const bool zx = !(fabs(d.x) >= 1.0e-30), zy = !(fabs(d.y) >= 1.0e-30), zz = !(fabs(d.z) >= 1.0e-30);
+  const bool zeroAny = zx | zy | zz;
+  const float ivx = (float)inv.x, ivy = (float)inv.y, ivz = (float)inv.z;
+  const bool negx = (d.x < 0.0) & !zx, negy = (d.y < 0.0) & !zy, negz = (d.z < 0.0) & !zz;
   // object-space ray of every identity-transform mesh (Geometry::intersect,
   // scene.cpp:17-20): position is unchanged, direction is ((p+d)-p) renormalised
   const V3 dirI = (p + d) - p;
@@ -573,48 +626,88 @@ __device__ int traceBvh(const DevScene& S, const V3& p, const V3& d, int rayType
 
   bool haveOne = false;
   double bestT = tLimit;   // doubles as the far cull bound until a hit exists
+  float bestTf = roundUpF(bestT);
   int bestPrim = RT_PRIM_NONE;
   BvhEntry stack[RT_BVH_STACK];
   int sp = 0;
   int ref = 0;
+  const float kInf = __int_as_float(0x7f800000);
   for (;;) {
     if (ref >= 0) {
-      const DevBvhNode n = S.bvh[ref];
+      const uint4* np = reinterpret_cast<const uint4*>(S.bvh + ref);
+      const uint4 w0 = np[0], w1 = np[1], w2 = np[2];
+      const uint2 w3 = *reinterpret_cast<const uint2*>(np + 3);
       if (STATS) cnt.nodes++;
-      // slab planes of child c on axis a: origin + q * 2^exp; with
-      // A = (origin - p) * inv and B = 2^exp * inv the plane distance is A + q*B
-      const double sx = pow2i(n.exp[0]) * inv.x, sy = pow2i(n.exp[1]) * inv.y, sz = pow2i(n.exp[2]) * inv.z;
-      const double ax = ((double)n.origin[0] - p.x) * inv.x, ay = ((double)n.origin[1] - p.y) * inv.y,
-                   az = ((double)n.origin[2] - p.z) * inv.z;
-      // distances of the four children (+inf when missed), kept in registers:
-      // every index below is a compile-time constant after unrolling
-      double tn[4];
-      int kid[4];
+      const float ox = __uint_as_float(w0.x), oy = __uint_as_float(w0.y), oz = __uint_as_float(w0.z);
+      const int ex = (int)(int8_t)(w0.w & 255u), ey = (int)(int8_t)((w0.w >> 8) & 255u),
+                ez = (int)(int8_t)((w0.w >> 16) & 255u);
+      int kid[4] = {(int)w1.x, (int)w1.y, (int)w1.z, (int)w1.w};
+      float tn[4];
+      // A = (origin - p) / d, B = 2^exp / d: plane q lies at distance A + q * B
+      const double ax = ((double)ox - p.x) * inv.x, ay = ((double)oy - p.y) * inv.y, az = ((double)oz - p.z) * inv.z;
+      float bx = ivx * pow2f(ex), by = ivy * pow2f(ey), bz = ivz * pow2f(ez);
+      const float afx = (float)ax, afy = (float)ay, afz = (float)az;
+      // rounding of A, of B and of the fused multiply-add: < 2^-23 (|A| + 255 |B|)
+      const float errx = 0x1p-22f * fmaf(255.0f, fabsf(bx), fabsf(afx));
+      const float erry = 0x1p-22f * fmaf(255.0f, fabsf(by), fabsf(afy));
+      const float errz = 0x1p-22f * fmaf(255.0f, fabsf(bz), fabsf(afz));
+      float a0x = afx - errx, a1x = afx + errx;
+      float a0y = afy - erry, a1y = afy + erry;
+      float a0z = afz - errz, a1z = afz + errz;
+      if (zeroAny) {
+        // The ray runs parallel to the slabs of this axis: with u = the origin in
+        // grid units, K (q_lo - u) and K (q_hi - u) for a huge K put the entry at
+        // -huge and the exit at +huge when the origin lies between the planes and
+        // the entry at +huge or the exit at -huge when it does not.
+        const float K = 0x1p40f;
+        if (zx) {
+          const float u = fminf(fmaxf((float)((p.x - (double)ox) * pow2i(-ex)), -1.0e9f), 1.0e9f);
+          const float m = fmaf(fabsf(u), 0x1p-21f, 0x1p-20f);
+          bx = K; a0x = -K * (u + m); a1x = -K * (u - m);
+        }
+        if (zy) {
+          const float u = fminf(fmaxf((float)((p.y - (double)oy) * pow2i(-ey)), -1.0e9f), 1.0e9f);
+          const float m = fmaf(fabsf(u), 0x1p-21f, 0x1p-20f);
+          by = K; a0y = -K * (u + m); a1y = -K * (u - m);
+        }
+        if (zz) {
+          const float u = fminf(fmaxf((float)((p.z - (double)oz) * pow2i(-ez)), -1.0e9f), 1.0e9f);
+          const float m = fmaf(fabsf(u), 0x1p-21f, 0x1p-20f);
+          bz = K; a0z = -K * (u + m); a1z = -K * (u - m);
+        }
+      }
+      // entry / exit plane words by the sign of the direction
+      const uint32_t q0x = negx ? w2.w : w2.x, q1x = negx ? w2.x : w2.w;
+      const uint32_t q0y = negy ? w3.x : w2.y, q1y = negy ? w2.y : w3.x;
+      const uint32_t q0z = negz ? w3.y : w2.z, q1z = negz ? w2.z : w3.y;
 #pragma unroll
-      for (int c = 0; c < 4; c++) {
-        const double x0 = ax + (double)n.qlo[c][0] * sx, x1 = ax + (double)n.qhi[c][0] * sx;
-        const double y0 = ay + (double)n.qlo[c][1] * sy, y1 = ay + (double)n.qhi[c][1] * sy;
-        const double z0 = az + (double)n.qlo[c][2] * sz, z1 = az + (double)n.qhi[c][2] * sz;
-        // fmin/fmax drop the NaN of 0 * inf (origin on a slab plane of an axis the ray is parallel to)
-        const double tnear = fmax(fmax(fmin(x0, x1), fmin(y0, y1)), fmax(fmin(z0, z1), 0.0));
-        const double tfar = fmin(fmin(fmax(x0, x1), fmax(y0, y1)), fmin(fmax(z0, z1), bestT));
-        const bool hit = n.child[c] != RT_BVH_EMPTY && tnear <= tfar * 1.000000000001 + 1e-12;
-        tn[c] = hit ? tnear : __longlong_as_double(0x7ff0000000000000LL);
-        kid[c] = n.child[c];
+      for (int c = 0; c < 4; c += 2) {
+        const rt_f2 nx = slab2(q0x, c, bx, a0x), fx = slab2(q1x, c, bx, a1x);
+        const rt_f2 ny = slab2(q0y, c, by, a0y), fy = slab2(q1y, c, by, a1y);
+        const rt_f2 nz = slab2(q0z, c, bz, a0z), fz = slab2(q1z, c, bz, a1z);
+        const float tnear0 = fmaxf(fmaxf(nx.x, ny.x), nz.x), tnear1 = fmaxf(fmaxf(nx.y, ny.y), nz.y);
+        const float tfar0 = fminf(fminf(fminf(fx.x, fy.x), fz.x), bestTf);
+        const float tfar1 = fminf(fminf(fminf(fx.y, fy.y), fz.y), bestTf);
+        const bool h0 = (kid[c] != RT_BVH_EMPTY) & (tnear0 <= tfar0) & (tfar0 >= 0.0f);
+        const bool h1 = (kid[c + 1] != RT_BVH_EMPTY) & (tnear1 <= tfar1) & (tfar1 >= 0.0f);
+        tn[c] = h0 ? tnear0 : kInf;
+        tn[c + 1] = h1 ? tnear1 : kInf;
       }
       // ascending sorting network on (tn, kid): (0,1)(2,3)(0,2)(1,3)(1,2)
 #define RT_CSWAP(i, j)                                                       \
-      if (tn[j] < tn[i]) {                                                   \
-        const double tt = tn[i]; tn[i] = tn[j]; tn[j] = tt;                  \
-        const int kk = kid[i]; kid[i] = kid[j]; kid[j] = kk;                 \
+      {                                                                      \
+        const bool sw = tn[j] < tn[i];                                       \
+        const float tlo = sw ? tn[j] : tn[i], thi = sw ? tn[i] : tn[j];      \
+        const int klo = sw ? kid[j] : kid[i], khi = sw ? kid[i] : kid[j];    \
+        tn[i] = tlo; tn[j] = thi; kid[i] = klo; kid[j] = khi;                \
       }
       RT_CSWAP(0, 1) RT_CSWAP(2, 3) RT_CSWAP(0, 2) RT_CSWAP(1, 3) RT_CSWAP(1, 2)
 #undef RT_CSWAP
-      if (tn[0] < 1.0e308) {
+      if (tn[0] < kInf) {
         // farthest first onto the stack, the nearest child is visited next
-        if (tn[3] < 1.0e308 && sp < RT_BVH_STACK) { stack[sp].ref = kid[3]; stack[sp].tn = roundDownF(tn[3]); sp++; }
-        if (tn[2] < 1.0e308 && sp < RT_BVH_STACK) { stack[sp].ref = kid[2]; stack[sp].tn = roundDownF(tn[2]); sp++; }
-        if (tn[1] < 1.0e308 && sp < RT_BVH_STACK) { stack[sp].ref = kid[1]; stack[sp].tn = roundDownF(tn[1]); sp++; }
+        if (tn[3] < kInf && sp < RT_BVH_STACK) { stack[sp].ref = kid[3]; stack[sp].tn = tn[3]; sp++; }
+        if (tn[2] < kInf && sp < RT_BVH_STACK) { stack[sp].ref = kid[2]; stack[sp].tn = tn[2]; sp++; }
+        if (tn[1] < kInf && sp < RT_BVH_STACK) { stack[sp].ref = kid[1]; stack[sp].tn = tn[1]; sp++; }
         ref = kid[0];
         continue;
       }
@@ -631,6 +724,7 @@ __device__ int traceBvh(const DevScene& S, const V3& p, const V3& d, int rayType
             if (occDist2 < 0.0 || length2(Qh - p) < occDist2) { tOut = t; return 0; }
           } else if (!haveOne || t < bestT) {
             haveOne = true; bestT = t; bestPrim = oi;
+            bestTf = roundUpF(bestT);
           }
         }
       } else {
@@ -654,6 +748,7 @@ __device__ int traceBvh(const DevScene& S, const V3& p, const V3& d, int rayType
             if (occDist2 < 0.0 || length2(Qh - p) < occDist2) { tOut = tw; return 0; }
           } else if (!haveOne || tw < bestT) {
             haveOne = true; bestT = tw; bestPrim = RT_PRIM_FACE | T.face;
+            bestTf = roundUpF(bestT);
           }
         }
       }

@@ -179,6 +179,37 @@ def test_intersect_batch_bit_exact(built):
         ds.close()
 
 
+def test_fast_traversal_axis_parallel_rays(built):
+    """Rays with one or two exactly-zero direction components (the middle pixel
+    column of an axis-aligned camera, mirror bounces off axis-aligned faces) must
+    find the same closest hit as the reference's linear scan; origins are put on
+    box faces and on the floor plane too."""
+    rng = np.random.RandomState(5)
+    for text in (common.all_primitives_scene(), common.small_mesh_scene(2), common.small_heightfield_scene(16)):
+        fast = host.HostScene(text=text)
+        lin = host.HostScene(text=text, kd_tree=False)
+        ds = device.DeviceScene(fast.desc_ptr)
+        n = 3000
+        p = rng.uniform(-5, 5, size=(n, 3)) + np.array([0.1371, 2.8137, 0.0])
+        p[::7, 1] = -0.02            # on the floor square of the primitives scene
+        p[::11, 0] = 0.1371          # the camera's x of that scene
+        tgt = rng.uniform(-2.5, 2.5, size=(n, 3)) + np.array([0, 0.8, 0])
+        d = tgt - p
+        zero = rng.randint(0, 7, size=n)       # bit a set: component a is zero
+        for a in range(3):
+            d[(zero >> a) & 1 == 1, a] = 0.0
+        d[zero == 7] = np.array([0.0, -1.0, 0.0])
+        d[::13] = np.where(d[::13] == 0.0, -0.0, d[::13])   # negative zeros as well
+        d /= np.linalg.norm(d, axis=1)[:, None]
+        rays = np.concatenate([p, d], axis=1)
+        ref = loader.intersect_batch(lin.desc_ptr, rays)
+        got = ds.intersect(rays, None, abi.RT_TRAVERSE_FAST)
+        bad = [k for k in range(n) if got[k].object_id != ref[k].object_id or got[k].t != ref[k].t]
+        assert not bad, (len(bad), [(k, list(rays[k]), got[k].object_id, ref[k].object_id, got[k].t, ref[k].t)
+                                    for k in bad[:5]])
+        ds.close()
+
+
 def test_sharded_tiles_assemble_to_single_device_frame(built):
     """Interleaved tile shards rendered one after the other on one GPU must
     assemble byte-identically into the single-shard frame (host and packed paths)."""
