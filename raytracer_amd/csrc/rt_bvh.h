@@ -51,7 +51,6 @@ struct Node {
 };
 static_assert(sizeof(Node) == 64, "BVH node must be 64 bytes");
 
-constexpr int kMaxLeaf = 4;
 constexpr int kBins = 16;
 constexpr int32_t kObjectBit = 0x40000000;
 
@@ -77,6 +76,7 @@ class Builder {
   Box rootBox;
   int maxDepth = 0;
   bool balanced = false;   // median splits only: depth <= log2(n) + 1
+  int maxLeaf = 2;         // triangles per leaf, 1..8 (the leaf reference holds count - 1 in 3 bits)
 
   // prims is consumed (reordered).  Returns false for an empty scene.
   bool build(std::vector<Prim>& prims) {
@@ -129,7 +129,7 @@ class Builder {
 
   bool leafAllowed(int first, int count) const {
     if (count == 1) return true;
-    if (count > kMaxLeaf) return false;
+    if (count > maxLeaf) return false;
     for (int i = first; i < first + count; i++)
       if ((*prims_)[i].id & kObjectBit) return false;  // objects sit alone in a leaf
     return true;

@@ -61,7 +61,6 @@ struct Pool {
   double* hitT; int* hitPrim;
   // shade points of the current level (indexed 0..nsp)
   double* spQ; double* spN;
-  double* lightD; double* lightS;                // [n_lights][3][cap]
   // persistent for the whole batch (pool slot / pool shade-point index)
   double* rayI;
   double* spShade;
@@ -163,8 +162,14 @@ __device__ __forceinline__ void flushCounters(const TraceCounters& c, Counters* 
   }
 }
 
+#ifdef RT_TRACE_WAVES
+#define RT_TRACE_ATTR __attribute__((amdgpu_waves_per_eu(RT_TRACE_WAVES, RT_TRACE_WAVES)))
+#else
+#define RT_TRACE_ATTR
+#endif
+
 template <bool FAST, bool STATS>
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kBlock) RT_TRACE_ATTR
 k_trace(DevScene S, int n, const double* rayP, const double* rayD, const int* rayType, size_t stride,
         double* hitT, int* hitPrim, Counters* counters) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -317,123 +322,135 @@ k_surface(DevScene S, int n, int items, int par, size_t rayOff, size_t spOff, in
   if (threadIdx.x == 0 && litCount) atomicAdd(&P.counters->litsp, (unsigned long long)litCount);
 }
 
-// One thread per (light, shade point): shadow ray and the two Phong terms of
-// Material::shade for that light (material.cpp:54-73, light.cpp:14-149).
+// Shadow ray and attenuation of one light at one shade point: the colour that
+// multiplies the Phong terms, distanceAttenuation * shadowAttenuation
+// (material.cpp:59-60, light.cpp:14-149), and the direction to the light.
 template <bool FAST, bool STATS>
-__global__ void __launch_bounds__(kBlock)
-k_lights(DevScene S, long long nMax, size_t spOff, Pool P) {
-  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const unsigned int nsp = P.counters->nsp;
-  TraceCounters tc{0, 0};
-  if (idx < nMax && idx < (long long)nsp * S.n_lights) {
-    const int li = (int)(idx / nsp);
-    const int s = (int)(idx % nsp);
-    const unsigned int mw = (unsigned int)P.spMat[spOff + s];
-    if (mw & RT_SPM_LIT) {
-      const RtLight& l = S.lights[li];
-      const V3 Q = loadV3(P.spQ, P.cap, s), N = loadV3(P.spN, P.cap, s);
-      const V3 color(l.color);
-      V3 atten;
-      V3 L;  // direction to the light as Material::shade normalises it
-      if (l.type == RT_LIGHT_DIRECTIONAL) {
-        const V3 sd = normalized(-V3(l.orientation));
-        L = sd;
-        double th;
-        int prim;
-        if (FAST) {
-          // any hit blacks a directional light out (light.cpp:21-24)
-          prim = traceBvh<true, STATS>(S, Q, sd, RT_RAY_SHADOW, 1.0e308, -1.0, th, tc);
+__device__ __forceinline__ V3 lightIntensityAt(const DevScene& S, const RtLight& l, const V3& Q, V3& L,
+                                               TraceCounters& tc) {
+  const V3 color(l.color);
+  V3 atten;
+  if (l.type == RT_LIGHT_DIRECTIONAL) {
+    const V3 sd = normalized(-V3(l.orientation));
+    L = sd;
+    double th;
+    int prim;
+    if (FAST) {
+      // any hit blacks a directional light out (light.cpp:21-24)
+      prim = traceBvh<true, STATS>(S, Q, sd, RT_RAY_SHADOW, 1.0e308, -1.0, th, tc);
+    } else {
+      prim = traceKdReference<STATS>(S, Q, sd, RT_RAY_SHADOW, th, tc);
+    }
+    atten = (prim != RT_PRIM_NONE) ? V3(0, 0, 0) : color;
+  } else {
+    const V3 position(l.position);
+    V3 sd = normalized(position - Q);
+    L = normalized(sd);  // getDirection normalises, shade normalises again
+    const double lightDistance = length2(position - Q);
+    double th;
+    // FAST: an occluder beyond the light is irrelevant; bound the search a
+    // little past the light so that the strict < below decides
+    const double limit = sqrt(lightDistance) * 1.0000001 + 1e-7;
+    int prim;
+    bool occluded = false;
+    V3 kt;
+    if (FAST && S.opaque) {
+      // Every material has kt == 0, so the filter colour of ANY occluder in
+      // front of the light is the closest occluder's: stop at the first one.
+      prim = traceBvh<true, STATS>(S, Q, sd, RT_RAY_SHADOW, limit, lightDistance, th, tc);
+      occluded = prim != RT_PRIM_NONE;
+      prim = RT_PRIM_NONE;
+    } else if (FAST) {
+      prim = traceBvh<false, STATS>(S, Q, sd, RT_RAY_SHADOW, limit, -1.0, th, tc);
+    } else {
+      prim = traceKdReference<STATS>(S, Q, sd, RT_RAY_SHADOW, th, tc);
+    }
+    if (prim != RT_PRIM_NONE) {
+      const V3 Qh = Q + (th * sd);
+      const double distanceSq = length2(Qh - Q);
+      if (distanceSq < lightDistance) {
+        occluded = true;
+        if ((prim & RT_PRIM_FACE) && S.smooth && S.vmaterials &&
+            S.meshes[S.objects[S.tris[prim & ~RT_PRIM_FACE].owner].mesh].has_vertex_materials) {
+          Surface sf;
+          MatD m;
+          surfaceAt(S, prim, Q, sd, RT_RAY_SHADOW, sf, &m, true);
+          kt = m.kt;
         } else {
-          prim = traceKdReference<STATS>(S, Q, sd, RT_RAY_SHADOW, th, tc);
-        }
-        atten = (prim != RT_PRIM_NONE) ? V3(0, 0, 0) : color;
-      } else {
-        const V3 position(l.position);
-        V3 sd = normalized(position - Q);
-        L = normalized(sd);  // getDirection normalises, shade normalises again
-        const double lightDistance = length2(position - Q);
-        double th;
-        // FAST: an occluder beyond the light is irrelevant; bound the search a
-        // little past the light so that the strict < below decides
-        const double limit = sqrt(lightDistance) * 1.0000001 + 1e-7;
-        int prim;
-        bool occluded = false;
-        V3 kt;
-        if (FAST && S.opaque) {
-          // Every material has kt == 0, so the filter colour of ANY occluder in
-          // front of the light is the closest occluder's: stop at the first one.
-          prim = traceBvh<true, STATS>(S, Q, sd, RT_RAY_SHADOW, limit, lightDistance, th, tc);
-          occluded = prim != RT_PRIM_NONE;
-          prim = RT_PRIM_NONE;
-        } else if (FAST) {
-          prim = traceBvh<false, STATS>(S, Q, sd, RT_RAY_SHADOW, limit, -1.0, th, tc);
-        } else {
-          prim = traceKdReference<STATS>(S, Q, sd, RT_RAY_SHADOW, th, tc);
-        }
-        if (prim != RT_PRIM_NONE) {
-          const V3 Qh = Q + (th * sd);
-          const double distanceSq = length2(Qh - Q);
-          if (distanceSq < lightDistance) {
-            occluded = true;
-            if ((prim & RT_PRIM_FACE) && S.smooth && S.vmaterials &&
-                S.meshes[S.objects[S.tris[prim & ~RT_PRIM_FACE].owner].mesh].has_vertex_materials) {
-              Surface sf;
-              MatD m;
-              surfaceAt(S, prim, Q, sd, RT_RAY_SHADOW, sf, &m, true);
-              kt = m.kt;
-            } else {
-              const int oi = (prim & RT_PRIM_FACE) ? S.tris[prim & ~RT_PRIM_FACE].owner : prim;
-              kt = V3(S.materials[S.objects[oi].material].kt);
-            }
-          }
-        }
-        if (l.type == RT_LIGHT_POINT) {
-          atten = occluded ? prod(kt, color) : color;
-        } else {
-          sd = sd * -1;
-          const V3 orientation(l.orientation);
-          const double angle = acos(dot(orientation, sd)) * 180 / M_PI;
-          if (angle > l.atten_angle) {
-            atten = V3(0.0, 0.0, 0.0);
-          } else {
-            const double fallFactor = pow(dot(orientation, sd), l.fall_rate);
-            atten = occluded ? prod((color * fallFactor), kt) : (color * fallFactor);
-          }
+          const int oi = (prim & RT_PRIM_FACE) ? S.tris[prim & ~RT_PRIM_FACE].owner : prim;
+          kt = V3(S.materials[S.objects[oi].material].kt);
         }
       }
-      const V3 lightIntensity = distanceAttenuation(l, Q) * atten;
-      V3 kd, ks;
+    }
+    if (l.type == RT_LIGHT_POINT) {
+      atten = occluded ? prod(kt, color) : color;
+    } else {
+      sd = sd * -1;
+      const V3 orientation(l.orientation);
+      const double angle = acos(dot(orientation, sd)) * 180 / M_PI;
+      if (angle > l.atten_angle) {
+        atten = V3(0.0, 0.0, 0.0);
+      } else {
+        const double fallFactor = pow(dot(orientation, sd), l.fall_rate);
+        atten = occluded ? prod((color * fallFactor), kt) : (color * fallFactor);
+      }
+    }
+  }
+  return distanceAttenuation(l, Q) * atten;
+}
+
+// One thread per shade point: Material::shade (material.cpp:41-75) -- the
+// emissive + ambient base, then per light in scene order the shadow ray and the
+// diffuse and specular terms, added in the reference's order.
+template <bool FAST, bool STATS>
+__global__ void __launch_bounds__(kBlock) RT_TRACE_ATTR
+k_lights(DevScene S, int nMax, size_t spOff, Pool P) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned int nsp = P.counters->nsp;
+  TraceCounters tc{0, 0};
+  if (s < nMax && (unsigned int)s < nsp) {
+    const size_t g = spOff + s;
+    const unsigned int mw = (unsigned int)P.spMat[g];
+    const bool interp = (mw & RT_SPM_INTERP) != 0;
+    if (mw & RT_SPM_LIT) {
+      V3 kd, ks, I;
       double shin;
-      if (mw & RT_SPM_INTERP) {
+      if (interp) {
         kd = loadV3(P.spKd, P.cap, s);
         ks = loadV3(P.spKs, P.cap, s);
         shin = P.spShin[s];
+        I = loadV3(P.spShade, P.cap, g);
       } else {
         const DevMat& dm = S.devMats[mw & RT_SPM_INDEX];
         kd = V3(dm.kd);
         ks = V3(dm.ks);
         shin = dm.shin;
+        I = V3(dm.base);
       }
-      const V3 D = prod(kd, lightIntensity) * fmax(dot(N, L), 0.0);
-      V3 Sp(0, 0, 0);
-      const bool hasKs = !iszero(ks);
-      if (hasKs) {
-        const V3 view = normalized(V3(S.eye) - Q);             // material.cpp:66-67
-        const V3 cosVector = N * dot(L, N);
-        const V3 sinVector = cosVector - L;
-        const V3 refl = normalized(cosVector + sinVector);
-        Sp = prod(ks, lightIntensity) * pow(fmax(dot(refl, view), 0.0), shin);
+      const bool hasKd = !iszero(kd), hasKs = !iszero(ks);
+      const V3 Q = loadV3(P.spQ, P.cap, s), N = loadV3(P.spN, P.cap, s);
+      for (int li = 0; li < S.n_lights; li++) {
+        const RtLight& l = S.lights[li];
+        V3 L;  // direction to the light as Material::shade normalises it
+        const V3 lightIntensity = lightIntensityAt<FAST, STATS>(S, l, Q, L, tc);
+        if (hasKd) I = I + prod(kd, lightIntensity) * fmax(dot(N, L), 0.0);
+        if (hasKs) {
+          const V3 view = normalized(V3(S.eye) - Q);             // material.cpp:66-67
+          const V3 cosVector = N * dot(L, N);
+          const V3 sinVector = cosVector - L;
+          const V3 refl = normalized(cosVector + sinVector);
+          I = I + prod(ks, lightIntensity) * pow(fmax(dot(refl, view), 0.0), shin);
+        }
       }
-      const size_t o = (size_t)li * 3 * P.cap;
-      if (!iszero(kd)) storeV3(P.lightD + o, P.cap, s, D);   // k_shade reads what it adds only
-      if (hasKs) storeV3(P.lightS + o, P.cap, s, Sp);
+      storeV3(P.spShade, P.cap, g, I);
+    } else if (!interp) {
+      storeV3(P.spShade, P.cap, g, V3(S.devMats[mw & RT_SPM_INDEX].base));
     }
   }
   if (STATS) flushCounters(tc, P.counters);
 }
 
-// In-order light sum of Material::shade, then the secondary rays of
-// RayTracer::traceRay (RayTracer.cpp:152-201).  Reflected rays of a tile are
+// The secondary rays of RayTracer::traceRay (RayTracer.cpp:152-201).  Reflected rays of a tile are
 // queued before its refracted rays.
 __global__ void __launch_bounds__(kBlock)
 k_shade(DevScene S, int nMax, int items, int par, size_t spOff, size_t rayOff, size_t nextRayOff,
@@ -442,7 +459,7 @@ k_shade(DevScene S, int nMax, int items, int par, size_t spOff, size_t rayOff, s
   const unsigned int nsp = min((unsigned int)nMax, P.counters->nsp);
   const int tileBase = blockIdx.x * kBlock * items;
   if ((unsigned int)tileBase >= nsp) return;   // whole block, uniform
-  // pass 1: light sum, and which children each shade point spawns
+  // pass 1: which children each shade point spawns
   unsigned int reflMask = 0, refrMask = 0;
   for (int k = 0; k < items; k++) {
     const int s = tileBase + k * kBlock + threadIdx.x;
@@ -452,19 +469,6 @@ k_shade(DevScene S, int nMax, int items, int par, size_t spOff, size_t rayOff, s
       const unsigned int mw = (unsigned int)P.spMat[g];
       const bool interp = (mw & RT_SPM_INTERP) != 0;
       const DevMat* dm = interp ? nullptr : &S.devMats[mw & RT_SPM_INDEX];
-      if (mw & RT_SPM_LIT) {
-        V3 I = interp ? loadV3(P.spShade, P.cap, g) : V3(dm->base);
-        const bool hasKd = interp ? !iszero(loadV3(P.spKd, P.cap, s)) : (dm->flags & RT_MATF_KD) != 0;
-        const bool hasKs = interp ? !iszero(loadV3(P.spKs, P.cap, s)) : (dm->flags & RT_MATF_KS) != 0;
-        for (int li = 0; li < S.n_lights; li++) {
-          const size_t o = (size_t)li * 3 * P.cap;
-          if (hasKd) I = I + loadV3(P.lightD + o, P.cap, s);
-          if (hasKs) I = I + loadV3(P.lightS + o, P.cap, s);
-        }
-        storeV3(P.spShade, P.cap, g, I);
-      } else if (!interp) {
-        storeV3(P.spShade, P.cap, g, V3(dm->base));
-      }
       if (depthLeft > 0) {
         wantRefl = interp ? !iszero(loadV3(P.spKr, P.cap, g)) : (dm->flags & RT_MATF_KR) != 0;
         if (interp ? !iszero(loadV3(P.spKt, P.cap, g)) : (dm->flags & RT_MATF_KT) != 0) {
@@ -851,8 +855,6 @@ int ensurePool(RtScene* sc, size_t cap) {
   POOL_ALLOC(P.hitPrim, int, cap);
   POOL_ALLOC(P.spQ, double, 3 * cap);
   POOL_ALLOC(P.spN, double, 3 * cap);
-  POOL_ALLOC(P.lightD, double, nl * 3 * cap);
-  POOL_ALLOC(P.lightS, double, nl * 3 * cap);
   POOL_ALLOC(P.rayI, double, 3 * cap);
   POOL_ALLOC(P.spShade, double, 3 * cap);
   POOL_ALLOC(P.spMat, int, cap);
@@ -875,7 +877,8 @@ int ensurePool(RtScene* sc, size_t cap) {
 
 size_t poolBytesPerSlot(int nLights, bool interp) {
   const size_t nl = (size_t)std::max(1, nLights);
-  return 2 * (48 + 4) + 12 + 24 * 2 + nl * 48 + 24 * 2 + 4 * 5 + (interp ? 24 * 4 + 8 * 2 : 0);
+  (void)nl;
+  return 2 * (48 + 4) + 12 + 24 * 2 + 24 * 2 + 4 * 5 + (interp ? 24 * 4 + 8 * 2 : 0);
 }
 
 struct TileLayout {
@@ -920,7 +923,7 @@ void launchTrace(RtScene* sc, int n, int par) {
       sc->dev, n, P.rayP[par], P.rayD[par], P.rayType[par], P.cap, P.hitT, P.hitPrim, P.counters);
 }
 template <bool FAST, bool STATS>
-void launchLights(RtScene* sc, long long nMax, size_t spOff) {
+void launchLights(RtScene* sc, int nMax, size_t spOff) {
   k_lights<FAST, STATS><<<gridFor(nMax), kBlock, 0, sc->stream>>>(sc->dev, nMax, spOff, sc->pool);
 }
 
@@ -967,8 +970,8 @@ int renderBatch(RenderCtx& cx, long long first, int count, long long* slotsUsed)
     k_surface<<<tiles, kBlock, 0, sc->stream>>>(sc->dev, n, items, par, rayOff, spOff, level,
                                                      rp.use_cubemap && sc->dev.cube_w > 0,
                                                      rp.filter_width, P);
-    const long long lightThreads = (long long)n * sc->dev.n_lights;
-    if (lightThreads > 0) {
+    const int lightThreads = n;   // one per possible shade point
+    {
       const bool timed2 = timedBegin(sc);
       if (cx.fast) { if (cx.wantStats) launchLights<true, true>(sc, lightThreads, spOff); else launchLights<true, false>(sc, lightThreads, spOff); }
       else { if (cx.wantStats) launchLights<false, true>(sc, lightThreads, spOff); else launchLights<false, false>(sc, lightThreads, spOff); }
@@ -1247,6 +1250,10 @@ int rt_scene_create(const RtSceneDesc* d, RtScene** out) {
     }
     rtbvh::Builder bvh;
     rtbvh::Collapser wide;
+    if (const char* e = std::getenv("RT_AMD_BVH_LEAF")) {   // tuning knob, 1..8 triangles per leaf
+      const int v = std::atoi(e);
+      if (v >= 1 && v <= 8) bvh.maxLeaf = v;
+    }
     D.bvh_valid = bvh.build(prims) ? 1 : 0;
     if (D.bvh_valid) {
       wide.run(bvh.nodes);

@@ -693,23 +693,41 @@ __device__ int traceBvh(const DevScene& S, const V3& p, const V3& d, int rayType
         tn[c] = h0 ? tnear0 : kInf;
         tn[c + 1] = h1 ? tnear1 : kInf;
       }
-      // ascending sorting network on (tn, kid): (0,1)(2,3)(0,2)(1,3)(1,2)
+      if (ANYHIT) {
+        // Every overlapped subtree has to be searched unless an occluder turns
+        // up, so only the descent wants an order: nearest child next, the
+        // others onto the stack as they come (no distance needed at the pop).
+        float tb = tn[0];
+        int kb = kid[0];
+#pragma unroll
+        for (int c = 1; c < 4; c++) {
+          const bool nearer = tn[c] < tb;
+          const float to = nearer ? tb : tn[c];
+          const int ko = nearer ? kb : kid[c];
+          tb = nearer ? tn[c] : tb;
+          kb = nearer ? kid[c] : kb;
+          if (to < kInf && sp < RT_BVH_STACK) { stack[sp].ref = ko; sp++; }
+        }
+        if (tb < kInf) { ref = kb; continue; }
+      } else {
+        // ascending sorting network on (tn, kid): (0,1)(2,3)(0,2)(1,3)(1,2)
 #define RT_CSWAP(i, j)                                                       \
-      {                                                                      \
-        const bool sw = tn[j] < tn[i];                                       \
-        const float tlo = sw ? tn[j] : tn[i], thi = sw ? tn[i] : tn[j];      \
-        const int klo = sw ? kid[j] : kid[i], khi = sw ? kid[i] : kid[j];    \
-        tn[i] = tlo; tn[j] = thi; kid[i] = klo; kid[j] = khi;                \
-      }
-      RT_CSWAP(0, 1) RT_CSWAP(2, 3) RT_CSWAP(0, 2) RT_CSWAP(1, 3) RT_CSWAP(1, 2)
+        {                                                                    \
+          const bool sw = tn[j] < tn[i];                                     \
+          const float tlo = sw ? tn[j] : tn[i], thi = sw ? tn[i] : tn[j];    \
+          const int klo = sw ? kid[j] : kid[i], khi = sw ? kid[i] : kid[j];  \
+          tn[i] = tlo; tn[j] = thi; kid[i] = klo; kid[j] = khi;              \
+        }
+        RT_CSWAP(0, 1) RT_CSWAP(2, 3) RT_CSWAP(0, 2) RT_CSWAP(1, 3) RT_CSWAP(1, 2)
 #undef RT_CSWAP
-      if (tn[0] < kInf) {
-        // farthest first onto the stack, the nearest child is visited next
-        if (tn[3] < kInf && sp < RT_BVH_STACK) { stack[sp].ref = kid[3]; stack[sp].tn = tn[3]; sp++; }
-        if (tn[2] < kInf && sp < RT_BVH_STACK) { stack[sp].ref = kid[2]; stack[sp].tn = tn[2]; sp++; }
-        if (tn[1] < kInf && sp < RT_BVH_STACK) { stack[sp].ref = kid[1]; stack[sp].tn = tn[1]; sp++; }
-        ref = kid[0];
-        continue;
+        if (tn[0] < kInf) {
+          // farthest first onto the stack, the nearest child is visited next
+          if (tn[3] < kInf && sp < RT_BVH_STACK) { stack[sp].ref = kid[3]; stack[sp].tn = tn[3]; sp++; }
+          if (tn[2] < kInf && sp < RT_BVH_STACK) { stack[sp].ref = kid[2]; stack[sp].tn = tn[2]; sp++; }
+          if (tn[1] < kInf && sp < RT_BVH_STACK) { stack[sp].ref = kid[1]; stack[sp].tn = tn[1]; sp++; }
+          ref = kid[0];
+          continue;
+        }
       }
     } else {
       const int x = ~ref;
@@ -754,12 +772,17 @@ __device__ int traceBvh(const DevScene& S, const V3& p, const V3& d, int rayType
       }
     }
     // pop the next subtree that can still contain a closer hit
-    bool found = false;
-    while (sp > 0) {
-      --sp;
-      if ((double)stack[sp].tn <= bestT) { ref = stack[sp].ref; found = true; break; }
+    if (ANYHIT) {
+      if (sp == 0) break;
+      ref = stack[--sp].ref;
+    } else {
+      bool found = false;
+      while (sp > 0) {
+        --sp;
+        if ((double)stack[sp].tn <= bestT) { ref = stack[sp].ref; found = true; break; }
+      }
+      if (!found) break;
     }
-    if (!found) break;
   }
   tOut = haveOne ? bestT : 0.0;
   return bestPrim;
