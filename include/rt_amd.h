@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RT_AMD_ABI_VERSION 1
+#define RT_AMD_ABI_VERSION 2
 
 typedef enum RtError {
   RT_OK = 0,
@@ -190,9 +190,13 @@ typedef struct RtStats {
   unsigned long long shade_points;
   double ms_total;           /* host wall time of the call */
   double ms_device;          /* HIP-event time of all kernels of the call */
-  double ms_trace;           /* HIP-event time spent in the traversal kernels */
-  int    trace_launches;
+  double ms_trace;           /* HIP-event time of the closest-hit launches (k_trace) */
+  int    trace_launches;     /* number of those launches */
   int    batches;
+  double ms_lights;          /* HIP-event time of the shading + shadow-ray launches (k_lights) */
+  int    lights_launches;
+  int    _pad;
+  unsigned long long shadow_nodes_visited, shadow_prims_tested;  /* shadow rays' share of the two totals */
 } RtStats;
 
 /* Result of Scene::intersect for one ray (isect, src/scene/ray.h:57-112). */

@@ -52,6 +52,7 @@ struct Counters {           // device-resident, zeroed per level / per call
   unsigned int overflow;    // pool exhausted
   unsigned int _pad;
   unsigned long long refl, refr, litsp, nodes, prims;
+  unsigned long long shadowNodes, shadowPrims;   // of the shadow rays (k_lights)
 };
 
 struct Pool {
@@ -148,7 +149,7 @@ k_raygen(DevScene S, FrameMap fm, long long firstPixelSlot, int nSamples, Pool P
   P.rayType[0][i] = RT_RAY_VISIBILITY;
 }
 
-__device__ __forceinline__ void flushCounters(const TraceCounters& c, Counters* g) {
+__device__ __forceinline__ void flushCounters(const TraceCounters& c, Counters* g, bool shadow) {
   // wave-level sum, one atomic per wavefront
   unsigned int n = c.nodes, t = c.prims;
 #pragma unroll
@@ -157,8 +158,8 @@ __device__ __forceinline__ void flushCounters(const TraceCounters& c, Counters* 
     t += __shfl_down(t, off);
   }
   if ((threadIdx.x & 63) == 0) {
-    atomicAdd(&g->nodes, (unsigned long long)n);
-    atomicAdd(&g->prims, (unsigned long long)t);
+    atomicAdd(shadow ? &g->shadowNodes : &g->nodes, (unsigned long long)n);
+    atomicAdd(shadow ? &g->shadowPrims : &g->prims, (unsigned long long)t);
   }
 }
 
@@ -186,7 +187,7 @@ k_trace(DevScene S, int n, const double* rayP, const double* rayD, const int* ra
     hitT[i] = t;
     hitPrim[i] = prim;
   }
-  if (STATS) flushCounters(tc, counters);
+  if (STATS) flushCounters(tc, counters, false);
 }
 
 // ---- queue compaction without a hot atomic ----------------------------------
@@ -447,7 +448,7 @@ k_lights(DevScene S, int nMax, size_t spOff, Pool P) {
       storeV3(P.spShade, P.cap, g, V3(S.devMats[mw & RT_SPM_INDEX].base));
     }
   }
-  if (STATS) flushCounters(tc, P.counters);
+  if (STATS) flushCounters(tc, P.counters, true);
 }
 
 // The secondary rays of RayTracer::traceRay (RayTracer.cpp:152-201).  Reflected rays of a tile are
@@ -778,6 +779,7 @@ struct RtScene {
   double* jitterDev = nullptr; size_t jitterCap = 0;
   std::vector<hipEvent_t> events;  // pairs around traversal kernels
   size_t eventsUsed = 0;
+  std::vector<unsigned char> eventKind;   // per pair: 0 k_trace, 1 k_lights
   hipEvent_t evStart = nullptr, evStop = nullptr;
 
   ~RtScene() {
@@ -938,8 +940,10 @@ bool timedBegin(RtScene* sc) {
   hipEventRecord(sc->events[sc->eventsUsed], sc->stream);
   return true;
 }
-void timedEnd(RtScene* sc) {
+void timedEnd(RtScene* sc, int kind) {
   hipEventRecord(sc->events[sc->eventsUsed + 1], sc->stream);
+  if (sc->eventKind.size() < sc->eventsUsed / 2 + 1) sc->eventKind.resize(sc->eventsUsed / 2 + 1);
+  sc->eventKind[sc->eventsUsed / 2] = (unsigned char)kind;
   sc->eventsUsed += 2;
 }
 
@@ -955,14 +959,14 @@ int renderBatch(RenderCtx& cx, long long first, int count, long long* slotsUsed)
   std::vector<LevelInfo> levels;
   int n = (int)nSamples, par = 0;
   size_t rayOff = 0, spOff = 0;
-  unsigned long long litTotal = 0, nodes = 0, prims = 0, refl = 0, refr = 0;
+  unsigned long long litTotal = 0, nodes = 0, prims = 0, refl = 0, refr = 0, snodes = 0, sprims = 0;
   k_raygen<<<gridFor(n), kBlock, 0, sc->stream>>>(sc->dev, cx.fm, first, n, P);
   for (int level = 0; level <= rp.depth && n > 0; level++) {
     HIP_TRY(hipMemsetAsync(P.counters, 0, sizeof(Counters), sc->stream));
     const bool timed = timedBegin(sc);
     if (cx.fast) { if (cx.wantStats) launchTrace<true, true>(sc, n, par); else launchTrace<true, false>(sc, n, par); }
     else { if (cx.wantStats) launchTrace<false, true>(sc, n, par); else launchTrace<false, false>(sc, n, par); }
-    if (timed) timedEnd(sc);
+    if (timed) timedEnd(sc, 0);
     cx.stats.trace_launches++;
     // entries per thread: enough tiles to fill the chip, few enough atomics
     const int items = std::min(kMaxItems, std::max(1, n / (kBlock * 2048)));
@@ -975,8 +979,8 @@ int renderBatch(RenderCtx& cx, long long first, int count, long long* slotsUsed)
       const bool timed2 = timedBegin(sc);
       if (cx.fast) { if (cx.wantStats) launchLights<true, true>(sc, lightThreads, spOff); else launchLights<true, false>(sc, lightThreads, spOff); }
       else { if (cx.wantStats) launchLights<false, true>(sc, lightThreads, spOff); else launchLights<false, false>(sc, lightThreads, spOff); }
-      if (timed2) timedEnd(sc);
-      cx.stats.trace_launches++;
+      if (timed2) timedEnd(sc, 1);
+      cx.stats.lights_launches++;
     }
     k_shade<<<tiles, kBlock, 0, sc->stream>>>(sc->dev, n, items, par, spOff, rayOff, rayOff + n,
                                               rp.depth - level, P);
@@ -988,6 +992,8 @@ int renderBatch(RenderCtx& cx, long long first, int count, long long* slotsUsed)
     litTotal += c.litsp;
     nodes += c.nodes;
     prims += c.prims;
+    snodes += c.shadowNodes;
+    sprims += c.shadowPrims;
     refl += c.refl;
     refr += c.refr;
     rayOff += n;
@@ -1010,8 +1016,10 @@ int renderBatch(RenderCtx& cx, long long first, int count, long long* slotsUsed)
   cx.stats.rays_reflect += refl;
   cx.stats.rays_refract += refr;
   cx.stats.rays_shadow += litTotal * (unsigned long long)sc->dev.n_lights;
-  cx.stats.nodes_visited += nodes;
-  cx.stats.prims_tested += prims;
+  cx.stats.nodes_visited += nodes + snodes;
+  cx.stats.prims_tested += prims + sprims;
+  cx.stats.shadow_nodes_visited += snodes;
+  cx.stats.shadow_prims_tested += sprims;
   for (const LevelInfo& L : levels) cx.stats.shade_points += (unsigned long long)L.nsp;
   cx.stats.batches++;
   *slotsUsed = (long long)std::max(rayOff, spOff);
@@ -1528,12 +1536,14 @@ int rt_render(RtScene* sc, const RtRenderParams* rp, unsigned char* rgb8_out, in
   float ms = 0.f;
   HIP_TRY(hipEventElapsedTime(&ms, sc->evStart, sc->evStop));
   cx.stats.ms_device = ms;
-  double traceMs = 0.0;
+  double traceMs = 0.0, lightsMs = 0.0;
   for (size_t e = 0; e + 1 < sc->eventsUsed; e += 2) {
     float m = 0.f;
-    if (hipEventElapsedTime(&m, sc->events[e], sc->events[e + 1]) == hipSuccess) traceMs += m;
+    if (hipEventElapsedTime(&m, sc->events[e], sc->events[e + 1]) == hipSuccess)
+      (sc->eventKind[e / 2] ? lightsMs : traceMs) += m;
   }
   cx.stats.ms_trace = traceMs;
+  cx.stats.ms_lights = lightsMs;
   cx.stats.ms_total =
       std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   if (stats_out) *stats_out = cx.stats;
