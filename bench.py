@@ -113,13 +113,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # RT_BENCH_FORCE_DIST=1: take the RCCL path (process group, gather, reductions)
+    # even with one rank, so that a single-GPU box can exercise it
+    use_dist = world > 1 or os.environ.get("RT_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP render path has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if use_dist:
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
     if world != args.gpus and rank == 0:
@@ -136,7 +140,7 @@ def main():
 
     def step():
         st = ds.render_device(p, packed.data_ptr())
-        bufs = parallel.gather_packed(packed, world, rank)
+        bufs = parallel.gather_packed(packed, world, rank, force=use_dist)
         if rank == 0:
             for r, b in enumerate(bufs):
                 device.unpack_tiles(b.data_ptr(), 3, width, height, TILE, TILE, r, world,
@@ -144,7 +148,7 @@ def main():
         return st
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -162,7 +166,7 @@ def main():
     elapsed = time.perf_counter() - t0
     tvals = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
     cvals = torch.tensor([float(rays)] + list(sums), dtype=torch.float64, device="cuda")
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tvals, op=dist.ReduceOp.MAX)
         dist.all_reduce(cvals, op=dist.ReduceOp.SUM)
     elapsed = float(tvals[0])
@@ -186,7 +190,7 @@ def main():
         svals = torch.tensor([float(sst.nodes_visited), float(sst.prims_tested), float(sst.rays_total),
                               float(sst.shadow_nodes_visited), float(sst.shadow_prims_tested),
                               float(sst.rays_shadow)], dtype=torch.float64, device="cuda")
-        if world > 1:
+        if use_dist:
             dist.all_reduce(svals, op=dist.ReduceOp.SUM)
         V, T, R, Vs, Ts, Rs = [float(x) for x in svals.tolist()]
         node_bytes = 64.0 if args.traversal == "fast" else 16.0
@@ -246,7 +250,7 @@ def main():
         }
         print(json.dumps(out), flush=True)
     ds.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

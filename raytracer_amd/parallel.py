@@ -51,12 +51,13 @@ def unpack_host(packed, frame, tile_w, tile_h, shard_index, shard_count):
     return frame
 
 
-def gather_packed(local_packed, world_size, rank, dst=0):
+def gather_packed(local_packed, world_size, rank, dst=0, force=False):
     """Gather equally sized (padded) packed buffers to `dst`.  local_packed is a
     torch tensor (pixels_padded, 3) uint8 on the backend's device.  Returns the
-    list of per-rank tensors on dst, None elsewhere."""
+    list of per-rank tensors on dst, None elsewhere.  A single rank skips the
+    collective unless `force` asks for it (to exercise the backend)."""
     import torch.distributed as dist
-    if world_size == 1:
+    if world_size == 1 and not force:
         return [local_packed]
     import torch
     bufs = [torch.empty_like(local_packed) for _ in range(world_size)] if rank == dst else None
