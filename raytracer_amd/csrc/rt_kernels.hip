@@ -65,6 +65,8 @@ struct Pool {
   // persistent for the whole batch (pool slot / pool shade-point index)
   double* rayI;
   double* spShade;
+  int* shPrim;                                   // [n_lights][cap] outcome of the shadow query per light
+  double* shT;                                   // [n_lights][cap] its hit parameter; NULL when the scene is opaque
   int* spMat;                                    // RT_SPM_* word: material index, lit flag
   int* spChildRefl; int* spChildRefr; int* spRayGlobal;
   // only for shade points whose material is interpolated from vertex materials
@@ -77,6 +79,7 @@ struct Pool {
 
 // Shade-point material word: index into DevScene::devMats, or RT_SPM_INTERP when
 // the material was interpolated and lives in the per-point arrays.
+#define RT_PRIM_ANY (-2)                         // shadow query: some occluder in front of the light
 #define RT_SPM_INTERP 0x80000000u
 #define RT_SPM_LIT 0x40000000u                   // kd or ks non-zero: lights contribute
 #define RT_SPM_INDEX 0x3fffffffu
@@ -169,6 +172,10 @@ __device__ __forceinline__ void flushCounters(const TraceCounters& c, Counters* 
 #define RT_TRACE_ATTR
 #endif
 
+// Closest hit of every ray of a level, one ray per thread.  (A streaming form in
+// which a wavefront refills finished lanes from a run of rays was measured 1.6x
+// slower on coherent rays: refilled lanes restart at the root and put the
+// wavefront's lanes out of phase between node and leaf work.)
 template <bool FAST, bool STATS>
 __global__ void __launch_bounds__(kBlock) RT_TRACE_ATTR
 k_trace(DevScene S, int n, const double* rayP, const double* rayD, const int* rayType, size_t stride,
@@ -323,49 +330,56 @@ k_surface(DevScene S, int n, int items, int par, size_t rayOff, size_t spOff, in
   if (threadIdx.x == 0 && litCount) atomicAdd(&P.counters->litsp, (unsigned long long)litCount);
 }
 
-// Shadow ray and attenuation of one light at one shade point: the colour that
-// multiplies the Phong terms, distanceAttenuation * shadowAttenuation
-// (material.cpp:59-60, light.cpp:14-149), and the direction to the light.
+// Shadow query of one light from shade point Q (light.cpp:14-31,66-98,112-149):
+// the closest occluder `prim` at parameter `th`, or, when the scene is opaque
+// and the traversal may stop at any occluder in front of the light, just
+// whether there is one (`anyOccluder`).
 template <bool FAST, bool STATS>
-__device__ __forceinline__ V3 lightIntensityAt(const DevScene& S, const RtLight& l, const V3& Q, V3& L,
-                                               TraceCounters& tc) {
+__device__ __forceinline__ void shadowQuery(const DevScene& S, const RtLight& l, const V3& Q, int& prim, double& th,
+                                            bool& anyOccluder, TraceCounters& tc) {
+  anyOccluder = false;
+  if (l.type == RT_LIGHT_DIRECTIONAL) {
+    const V3 sd = normalized(-V3(l.orientation));
+    // any hit blacks a directional light out (light.cpp:21-24)
+    if (FAST) prim = traceBvh<true, STATS>(S, Q, sd, RT_RAY_SHADOW, 1.0e308, -1.0, th, tc);
+    else prim = traceKdReference<STATS>(S, Q, sd, RT_RAY_SHADOW, th, tc);
+    return;
+  }
+  const V3 position(l.position);
+  const V3 sd = normalized(position - Q);
+  const double lightDistance = length2(position - Q);
+  // FAST: an occluder beyond the light is irrelevant; bound the search a little
+  // past the light so that the strict < of the caller decides
+  const double limit = sqrt(lightDistance) * 1.0000001 + 1e-7;
+  if (FAST && S.opaque) {
+    // Every material has kt == 0, so the filter colour of ANY occluder in
+    // front of the light is the closest occluder's: stop at the first one.
+    anyOccluder = traceBvh<true, STATS>(S, Q, sd, RT_RAY_SHADOW, limit, lightDistance, th, tc) != RT_PRIM_NONE;
+    prim = RT_PRIM_NONE;
+  } else if (FAST) {
+    prim = traceBvh<false, STATS>(S, Q, sd, RT_RAY_SHADOW, limit, -1.0, th, tc);
+  } else {
+    prim = traceKdReference<STATS>(S, Q, sd, RT_RAY_SHADOW, th, tc);
+  }
+}
+
+// distanceAttenuation * shadowAttenuation of one light (material.cpp:59-60,
+// light.cpp:14-149) from the outcome of its shadow query, and the direction L
+// to the light as Material::shade normalises it.
+__device__ __forceinline__ V3 lightIntensityFrom(const DevScene& S, const RtLight& l, const V3& Q, int prim, double th,
+                                                 bool anyOccluder, V3& L) {
   const V3 color(l.color);
   V3 atten;
   if (l.type == RT_LIGHT_DIRECTIONAL) {
-    const V3 sd = normalized(-V3(l.orientation));
-    L = sd;
-    double th;
-    int prim;
-    if (FAST) {
-      // any hit blacks a directional light out (light.cpp:21-24)
-      prim = traceBvh<true, STATS>(S, Q, sd, RT_RAY_SHADOW, 1.0e308, -1.0, th, tc);
-    } else {
-      prim = traceKdReference<STATS>(S, Q, sd, RT_RAY_SHADOW, th, tc);
-    }
+    L = normalized(-V3(l.orientation));
     atten = (prim != RT_PRIM_NONE) ? V3(0, 0, 0) : color;
   } else {
     const V3 position(l.position);
     V3 sd = normalized(position - Q);
     L = normalized(sd);  // getDirection normalises, shade normalises again
     const double lightDistance = length2(position - Q);
-    double th;
-    // FAST: an occluder beyond the light is irrelevant; bound the search a
-    // little past the light so that the strict < below decides
-    const double limit = sqrt(lightDistance) * 1.0000001 + 1e-7;
-    int prim;
-    bool occluded = false;
+    bool occluded = anyOccluder;
     V3 kt;
-    if (FAST && S.opaque) {
-      // Every material has kt == 0, so the filter colour of ANY occluder in
-      // front of the light is the closest occluder's: stop at the first one.
-      prim = traceBvh<true, STATS>(S, Q, sd, RT_RAY_SHADOW, limit, lightDistance, th, tc);
-      occluded = prim != RT_PRIM_NONE;
-      prim = RT_PRIM_NONE;
-    } else if (FAST) {
-      prim = traceBvh<false, STATS>(S, Q, sd, RT_RAY_SHADOW, limit, -1.0, th, tc);
-    } else {
-      prim = traceKdReference<STATS>(S, Q, sd, RT_RAY_SHADOW, th, tc);
-    }
     if (prim != RT_PRIM_NONE) {
       const V3 Qh = Q + (th * sd);
       const double distanceSq = length2(Qh - Q);
@@ -400,55 +414,83 @@ __device__ __forceinline__ V3 lightIntensityAt(const DevScene& S, const RtLight&
   return distanceAttenuation(l, Q) * atten;
 }
 
-// One thread per shade point: Material::shade (material.cpp:41-75) -- the
-// emissive + ambient base, then per light in scene order the shadow ray and the
-// diffuse and specular terms, added in the reference's order.
+// One thread per (light, shade point): the shadow query, nothing else, so that
+// the kernel's register budget is the traversal's (the Phong terms need pow and
+// acos, whose double-precision library code would nearly double it and halve
+// the wavefronts that hide the traversal's memory latency).
 template <bool FAST, bool STATS>
 __global__ void __launch_bounds__(kBlock) RT_TRACE_ATTR
-k_lights(DevScene S, int nMax, size_t spOff, Pool P) {
-  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+k_shadow(DevScene S, long long nMax, size_t spOff, Pool P) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const unsigned int nsp = P.counters->nsp;
   TraceCounters tc{0, 0};
-  if (s < nMax && (unsigned int)s < nsp) {
-    const size_t g = spOff + s;
-    const unsigned int mw = (unsigned int)P.spMat[g];
-    const bool interp = (mw & RT_SPM_INTERP) != 0;
-    if (mw & RT_SPM_LIT) {
-      V3 kd, ks, I;
-      double shin;
-      if (interp) {
-        kd = loadV3(P.spKd, P.cap, s);
-        ks = loadV3(P.spKs, P.cap, s);
-        shin = P.spShin[s];
-        I = loadV3(P.spShade, P.cap, g);
-      } else {
-        const DevMat& dm = S.devMats[mw & RT_SPM_INDEX];
-        kd = V3(dm.kd);
-        ks = V3(dm.ks);
-        shin = dm.shin;
-        I = V3(dm.base);
-      }
-      const bool hasKd = !iszero(kd), hasKs = !iszero(ks);
-      const V3 Q = loadV3(P.spQ, P.cap, s), N = loadV3(P.spN, P.cap, s);
-      for (int li = 0; li < S.n_lights; li++) {
-        const RtLight& l = S.lights[li];
-        V3 L;  // direction to the light as Material::shade normalises it
-        const V3 lightIntensity = lightIntensityAt<FAST, STATS>(S, l, Q, L, tc);
-        if (hasKd) I = I + prod(kd, lightIntensity) * fmax(dot(N, L), 0.0);
-        if (hasKs) {
-          const V3 view = normalized(V3(S.eye) - Q);             // material.cpp:66-67
-          const V3 cosVector = N * dot(L, N);
-          const V3 sinVector = cosVector - L;
-          const V3 refl = normalized(cosVector + sinVector);
-          I = I + prod(ks, lightIntensity) * pow(fmax(dot(refl, view), 0.0), shin);
-        }
-      }
-      storeV3(P.spShade, P.cap, g, I);
-    } else if (!interp) {
-      storeV3(P.spShade, P.cap, g, V3(S.devMats[mw & RT_SPM_INDEX].base));
+  if (idx < nMax && idx < (long long)nsp * S.n_lights) {
+    const int li = (int)(idx / nsp);
+    const int s = (int)(idx % nsp);
+    if ((unsigned int)P.spMat[spOff + s] & RT_SPM_LIT) {
+      const V3 Q = loadV3(P.spQ, P.cap, s);
+      int prim;
+      double th;
+      bool anyOccluder;
+      shadowQuery<FAST, STATS>(S, S.lights[li], Q, prim, th, anyOccluder, tc);
+      const size_t o = (size_t)li * P.cap + s;
+      P.shPrim[o] = anyOccluder ? RT_PRIM_ANY : prim;
+      if (P.shT) P.shT[o] = th;
     }
   }
   if (STATS) flushCounters(tc, P.counters, true);
+}
+
+// One thread per shade point: Material::shade (material.cpp:41-75) -- the
+// emissive + ambient base, then per light in scene order the attenuation from
+// its shadow query and the diffuse and specular terms, added in the
+// reference's order.
+__global__ void __launch_bounds__(kBlock)
+k_lights(DevScene S, int nMax, size_t spOff, Pool P) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned int nsp = P.counters->nsp;
+  if (s >= nMax || (unsigned int)s >= nsp) return;
+  const size_t g = spOff + s;
+  const unsigned int mw = (unsigned int)P.spMat[g];
+  const bool interp = (mw & RT_SPM_INTERP) != 0;
+  if (!(mw & RT_SPM_LIT)) {
+    // an interpolated material's base is already in spShade (k_surface)
+    if (!interp) storeV3(P.spShade, P.cap, g, V3(S.devMats[mw & RT_SPM_INDEX].base));
+    return;
+  }
+  V3 kd, ks, I;
+  double shin;
+  if (interp) {
+    kd = loadV3(P.spKd, P.cap, s);
+    ks = loadV3(P.spKs, P.cap, s);
+    shin = P.spShin[s];
+    I = loadV3(P.spShade, P.cap, g);
+  } else {
+    const DevMat& dm = S.devMats[mw & RT_SPM_INDEX];
+    kd = V3(dm.kd);
+    ks = V3(dm.ks);
+    shin = dm.shin;
+    I = V3(dm.base);
+  }
+  const bool hasKd = !iszero(kd), hasKs = !iszero(ks);
+  const V3 Q = loadV3(P.spQ, P.cap, s), N = loadV3(P.spN, P.cap, s);
+  for (int li = 0; li < S.n_lights; li++) {
+    const size_t o = (size_t)li * P.cap + s;
+    const int sp = P.shPrim[o];
+    const double th = P.shT ? P.shT[o] : 0.0;
+    V3 L;
+    const V3 lightIntensity = lightIntensityFrom(S, S.lights[li], Q, sp == RT_PRIM_ANY ? RT_PRIM_NONE : sp, th,
+                                                 sp == RT_PRIM_ANY, L);
+    if (hasKd) I = I + prod(kd, lightIntensity) * fmax(dot(N, L), 0.0);
+    if (hasKs) {
+      const V3 view = normalized(V3(S.eye) - Q);             // material.cpp:66-67
+      const V3 cosVector = N * dot(L, N);
+      const V3 sinVector = cosVector - L;
+      const V3 refl = normalized(cosVector + sinVector);
+      I = I + prod(ks, lightIntensity) * pow(fmax(dot(refl, view), 0.0), shin);
+    }
+  }
+  storeV3(P.spShade, P.cap, g, I);
 }
 
 // The secondary rays of RayTracer::traceRay (RayTracer.cpp:152-201).  Reflected rays of a tile are
@@ -857,6 +899,9 @@ int ensurePool(RtScene* sc, size_t cap) {
   POOL_ALLOC(P.hitPrim, int, cap);
   POOL_ALLOC(P.spQ, double, 3 * cap);
   POOL_ALLOC(P.spN, double, 3 * cap);
+  POOL_ALLOC(P.shPrim, int, nl * cap);
+  if (sc->dev.opaque) P.shT = nullptr;
+  else POOL_ALLOC(P.shT, double, nl * cap);
   POOL_ALLOC(P.rayI, double, 3 * cap);
   POOL_ALLOC(P.spShade, double, 3 * cap);
   POOL_ALLOC(P.spMat, int, cap);
@@ -877,10 +922,9 @@ int ensurePool(RtScene* sc, size_t cap) {
   return RT_OK;
 }
 
-size_t poolBytesPerSlot(int nLights, bool interp) {
+size_t poolBytesPerSlot(int nLights, bool interp, bool opaque) {
   const size_t nl = (size_t)std::max(1, nLights);
-  (void)nl;
-  return 2 * (48 + 4) + 12 + 24 * 2 + 24 * 2 + 4 * 5 + (interp ? 24 * 4 + 8 * 2 : 0);
+  return 2 * (48 + 4) + 12 + 24 * 2 + 24 * 2 + 4 * 5 + nl * (opaque ? 4 : 12) + (interp ? 24 * 4 + 8 * 2 : 0);
 }
 
 struct TileLayout {
@@ -925,8 +969,8 @@ void launchTrace(RtScene* sc, int n, int par) {
       sc->dev, n, P.rayP[par], P.rayD[par], P.rayType[par], P.cap, P.hitT, P.hitPrim, P.counters);
 }
 template <bool FAST, bool STATS>
-void launchLights(RtScene* sc, int nMax, size_t spOff) {
-  k_lights<FAST, STATS><<<gridFor(nMax), kBlock, 0, sc->stream>>>(sc->dev, nMax, spOff, sc->pool);
+void launchShadow(RtScene* sc, long long nMax, size_t spOff) {
+  k_shadow<FAST, STATS><<<gridFor(nMax), kBlock, 0, sc->stream>>>(sc->dev, nMax, spOff, sc->pool);
 }
 
 bool timedBegin(RtScene* sc) {
@@ -974,14 +1018,15 @@ int renderBatch(RenderCtx& cx, long long first, int count, long long* slotsUsed)
     k_surface<<<tiles, kBlock, 0, sc->stream>>>(sc->dev, n, items, par, rayOff, spOff, level,
                                                      rp.use_cubemap && sc->dev.cube_w > 0,
                                                      rp.filter_width, P);
-    const int lightThreads = n;   // one per possible shade point
-    {
+    const long long shadowThreads = (long long)n * sc->dev.n_lights;
+    if (shadowThreads > 0) {
       const bool timed2 = timedBegin(sc);
-      if (cx.fast) { if (cx.wantStats) launchLights<true, true>(sc, lightThreads, spOff); else launchLights<true, false>(sc, lightThreads, spOff); }
-      else { if (cx.wantStats) launchLights<false, true>(sc, lightThreads, spOff); else launchLights<false, false>(sc, lightThreads, spOff); }
+      if (cx.fast) { if (cx.wantStats) launchShadow<true, true>(sc, shadowThreads, spOff); else launchShadow<true, false>(sc, shadowThreads, spOff); }
+      else { if (cx.wantStats) launchShadow<false, true>(sc, shadowThreads, spOff); else launchShadow<false, false>(sc, shadowThreads, spOff); }
       if (timed2) timedEnd(sc, 1);
       cx.stats.lights_launches++;
     }
+    k_lights<<<gridFor(n), kBlock, 0, sc->stream>>>(sc->dev, n, spOff, P);
     k_shade<<<tiles, kBlock, 0, sc->stream>>>(sc->dev, n, items, par, spOff, rayOff, rayOff + n,
                                               rp.depth - level, P);
     Counters c;
@@ -1402,8 +1447,9 @@ int rt_render(RtScene* sc, const RtRenderParams* rp, unsigned char* rgb8_out, in
       sc->growthDepth = rp->depth;
     }
     const bool interp = sc->dev.interp_materials != 0;
-    const size_t perSlot = poolBytesPerSlot(sc->nLights, interp);
-    size_t cap = workspaceBudgetBytes(sc->pool.cap * poolBytesPerSlot((int)sc->poolLights, interp)) / perSlot;
+    const bool opaque = sc->dev.opaque != 0;
+    const size_t perSlot = poolBytesPerSlot(sc->nLights, interp, opaque);
+    size_t cap = workspaceBudgetBytes(sc->pool.cap * poolBytesPerSlot((int)sc->poolLights, interp, opaque)) / perSlot;
     const long long slots = (long long)TL.nTiles * rp->tile_w * rp->tile_h * nsFull;
     const size_t want = (size_t)std::max<double>((double)slots * sc->growth * 1.1, 1 << 16);
     cap = std::min(cap, want);

@@ -567,40 +567,205 @@ __device__ __forceinline__ rt_f2 slab2(uint32_t q, int c, float B, float A) {
   return __builtin_elementwise_fma(qf, b, a);
 }
 
+// ---- pieces of the BVH query, shared by the per-ray and the streaming form ----
+
+// What a query keeps per ray besides p and d.
+struct BvhRay {
+  V3 inv;                 // 1 / d
+  V3 ldI;                 // object-space direction of every identity-transform mesh
+  double lenI;            // (Geometry::intersect, scene.cpp:17-20: ((p+d)-p) renormalised)
+  float ivx, ivy, ivz;    // inv rounded to binary32
+  bool negx, negy, negz;  // direction sign per axis (false on a degenerate axis)
+  bool zx, zy, zz;        // |d| < 1e-30 on that axis: inside / outside test instead of a slab
+  bool cullBack;
+};
+
+__device__ __forceinline__ void bvhRaySetup(const DevScene& S, const V3& p, const V3& d, int rayType, BvhRay& r) {
+  r.cullBack = S.cull && rayType != RT_RAY_REFRACTION;
+  r.inv = V3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
+  r.zx = !(fabs(d.x) >= 1.0e-30);
+  r.zy = !(fabs(d.y) >= 1.0e-30);
+  r.zz = !(fabs(d.z) >= 1.0e-30);
+  r.ivx = (float)r.inv.x; r.ivy = (float)r.inv.y; r.ivz = (float)r.inv.z;
+  r.negx = (d.x < 0.0) & !r.zx;
+  r.negy = (d.y < 0.0) & !r.zy;
+  r.negz = (d.z < 0.0) & !r.zz;
+  const V3 dirI = (p + d) - p;
+  r.lenI = length(dirI);
+  r.ldI = V3(dirI.x / r.lenI, dirI.y / r.lenI, dirI.z / r.lenI);
+}
+
+// A NaN ray.  A refraction past the critical angle leaves a NaN direction
+// (RayTracer.cpp:193-199), and a hit of such a ray a NaN shade point.  No
+// comparison on a NaN orders anything, so no box can be culled; the reference's
+// scan over Scene::objects (scene.cpp:144-153) then accepts the first object
+// whose tests all fall through, and no triangle (trimesh.cpp:91-208 ends in
+// range checks).
+template <bool STATS>
+__device__ __forceinline__ int bvhScanNaN(const DevScene& S, const V3& p, const V3& d, double& tOut, TraceCounters& cnt) {
+  bool have = false;
+  double bt = 0.0;
+  int bp = RT_PRIM_NONE;
+  for (int j = 0; j < S.n_objects; j++) {
+    const RtObject& o = S.objects[j];
+    if (o.kind == RT_OBJ_TRIMESH) continue;
+    double t;
+    V3 N;
+    if (STATS) cnt.prims++;
+    if (objectIntersect<false>(o, p, d, t, N) && (!have || t < bt)) { have = true; bt = t; bp = j; }
+  }
+  tOut = bt;
+  return bp;
+}
+
+// Slab tests of the four children of node `ref`: tn[c] = entry distance (a
+// lower bound) of child c, +inf when the ray misses it or it lies beyond
+// bestTf; kid[c] = its reference.
+//
+// The box tests only decide which subtrees are skipped, never a result, so they
+// run in binary32 with every plane distance widened by a bound of its rounding
+// error (entry distances are lower bounds, exit distances upper bounds).
+__device__ __forceinline__ void bvhNodeSlabs(const DevScene& S, const V3& p, const BvhRay& r, int ref, float bestTf,
+                                             float tn[4], int kid[4]) {
+  const float kInf = __int_as_float(0x7f800000);
+  const uint4* np = reinterpret_cast<const uint4*>(S.bvh + ref);
+  const uint4 w0 = np[0], w1 = np[1], w2 = np[2];
+  const uint2 w3 = *reinterpret_cast<const uint2*>(np + 3);
+  const float ox = __uint_as_float(w0.x), oy = __uint_as_float(w0.y), oz = __uint_as_float(w0.z);
+  const int ex = (int)(int8_t)(w0.w & 255u), ey = (int)(int8_t)((w0.w >> 8) & 255u),
+            ez = (int)(int8_t)((w0.w >> 16) & 255u);
+  kid[0] = (int)w1.x; kid[1] = (int)w1.y; kid[2] = (int)w1.z; kid[3] = (int)w1.w;
+  // A = (origin - p) / d, B = 2^exp / d: plane q lies at distance A + q * B
+  const double ax = ((double)ox - p.x) * r.inv.x, ay = ((double)oy - p.y) * r.inv.y, az = ((double)oz - p.z) * r.inv.z;
+  float bx = r.ivx * pow2f(ex), by = r.ivy * pow2f(ey), bz = r.ivz * pow2f(ez);
+  const float afx = (float)ax, afy = (float)ay, afz = (float)az;
+  // rounding of A, of B and of the fused multiply-add: < 2^-23 (|A| + 255 |B|)
+  const float errx = 0x1p-22f * fmaf(255.0f, fabsf(bx), fabsf(afx));
+  const float erry = 0x1p-22f * fmaf(255.0f, fabsf(by), fabsf(afy));
+  const float errz = 0x1p-22f * fmaf(255.0f, fabsf(bz), fabsf(afz));
+  float a0x = afx - errx, a1x = afx + errx;
+  float a0y = afy - erry, a1y = afy + erry;
+  float a0z = afz - errz, a1z = afz + errz;
+  if (r.zx | r.zy | r.zz) {
+    // The ray runs parallel to the slabs of this axis: with u = the origin in
+    // grid units, K (q_lo - u) and K (q_hi - u) for a huge K put the entry at
+    // -huge and the exit at +huge when the origin lies between the planes and
+    // the entry at +huge or the exit at -huge when it does not.
+    const float K = 0x1p40f;
+    if (r.zx) {
+      const float u = fminf(fmaxf((float)((p.x - (double)ox) * pow2i(-ex)), -1.0e9f), 1.0e9f);
+      const float m = fmaf(fabsf(u), 0x1p-21f, 0x1p-20f);
+      bx = K; a0x = -K * (u + m); a1x = -K * (u - m);
+    }
+    if (r.zy) {
+      const float u = fminf(fmaxf((float)((p.y - (double)oy) * pow2i(-ey)), -1.0e9f), 1.0e9f);
+      const float m = fmaf(fabsf(u), 0x1p-21f, 0x1p-20f);
+      by = K; a0y = -K * (u + m); a1y = -K * (u - m);
+    }
+    if (r.zz) {
+      const float u = fminf(fmaxf((float)((p.z - (double)oz) * pow2i(-ez)), -1.0e9f), 1.0e9f);
+      const float m = fmaf(fabsf(u), 0x1p-21f, 0x1p-20f);
+      bz = K; a0z = -K * (u + m); a1z = -K * (u - m);
+    }
+  }
+  // entry / exit plane words by the sign of the direction
+  const uint32_t q0x = r.negx ? w2.w : w2.x, q1x = r.negx ? w2.x : w2.w;
+  const uint32_t q0y = r.negy ? w3.x : w2.y, q1y = r.negy ? w2.y : w3.x;
+  const uint32_t q0z = r.negz ? w3.y : w2.z, q1z = r.negz ? w2.z : w3.y;
+#pragma unroll
+  for (int c = 0; c < 4; c += 2) {
+    const rt_f2 nx = slab2(q0x, c, bx, a0x), fx = slab2(q1x, c, bx, a1x);
+    const rt_f2 ny = slab2(q0y, c, by, a0y), fy = slab2(q1y, c, by, a1y);
+    const rt_f2 nz = slab2(q0z, c, bz, a0z), fz = slab2(q1z, c, bz, a1z);
+    const float tnear0 = fmaxf(fmaxf(nx.x, ny.x), nz.x), tnear1 = fmaxf(fmaxf(nx.y, ny.y), nz.y);
+    const float tfar0 = fminf(fminf(fminf(fx.x, fy.x), fz.x), bestTf);
+    const float tfar1 = fminf(fminf(fminf(fx.y, fy.y), fz.y), bestTf);
+    const bool h0 = (kid[c] != RT_BVH_EMPTY) & (tnear0 <= tfar0) & (tfar0 >= 0.0f);
+    const bool h1 = (kid[c + 1] != RT_BVH_EMPTY) & (tnear1 <= tfar1) & (tfar1 >= 0.0f);
+    tn[c] = h0 ? tnear0 : kInf;
+    tn[c + 1] = h1 ? tnear1 : kInf;
+  }
+}
+
+// (tn, kid) ascending by tn: network (0,1)(2,3)(0,2)(1,3)(1,2)
+__device__ __forceinline__ void bvhSort4(float tn[4], int kid[4]) {
+#define RT_CSWAP(i, j)                                                 \
+  {                                                                    \
+    const bool sw = tn[j] < tn[i];                                     \
+    const float tlo = sw ? tn[j] : tn[i], thi = sw ? tn[i] : tn[j];    \
+    const int klo = sw ? kid[j] : kid[i], khi = sw ? kid[i] : kid[j];  \
+    tn[i] = tlo; tn[j] = thi; kid[i] = klo; kid[j] = khi;              \
+  }
+  RT_CSWAP(0, 1) RT_CSWAP(2, 3) RT_CSWAP(0, 2) RT_CSWAP(1, 3) RT_CSWAP(1, 2)
+#undef RT_CSWAP
+}
+
+// The primitives of leaf reference `ref` (< 0).  Closest hit: updates the best
+// hit.  Occlusion: returns true at the first hit that satisfies the reference's
+// test |(p + t d) - p|^2 < occDist2 (occDist2 < 0: any hit), with tHit set.
+template <bool ANYHIT, bool STATS>
+__device__ __forceinline__ bool bvhLeaf(const DevScene& S, const V3& p, const V3& d, const BvhRay& r, int ref,
+                                        double occDist2, bool& haveOne, double& bestT, float& bestTf, int& bestPrim,
+                                        double& tHit, TraceCounters& cnt) {
+  const int x = ~ref;
+  if (x & RT_BVH_OBJECT_BIT) {
+    const int oi = x & 0x3fffffff;
+    double t;
+    V3 N;
+    if (STATS) cnt.prims++;
+    if (objectIntersect<false>(S.objects[oi], p, d, t, N)) {
+      if (ANYHIT) {
+        const V3 Qh = p + (t * d);
+        if (occDist2 < 0.0 || length2(Qh - p) < occDist2) { tHit = t; return true; }
+      } else if (!haveOne || t < bestT) {
+        haveOne = true; bestT = t; bestPrim = oi;
+        bestTf = roundUpF(bestT);
+      }
+    }
+  } else {
+    const int first = x >> 3, count = (x & 7) + 1;
+    for (int k = 0; k < count; k++) {
+      const DevTri& T = S.bvhTris[first + k];
+      if (STATS) cnt.prims++;
+      double rt, tw;
+      bool hit;
+      if (T.axes & 16) {
+        hit = triTest<true>(T, p, r.ldI, r.cullBack, rt, nullptr);
+        tw = rt / r.lenI;
+      } else {
+        const LocalRay lr = toLocal(S.objects[T.owner].inverse, p, d);
+        hit = triTest<true>(T, lr.p, lr.d, r.cullBack, rt, nullptr);
+        tw = rt / lr.len;
+      }
+      if (!hit) continue;
+      if (ANYHIT) {
+        const V3 Qh = p + (tw * d);
+        if (occDist2 < 0.0 || length2(Qh - p) < occDist2) { tHit = tw; return true; }
+      } else if (!haveOne || tw < bestT) {
+        haveOne = true; bestT = tw; bestPrim = RT_PRIM_FACE | T.face;
+        bestTf = roundUpF(bestT);
+      }
+    }
+  }
+  return false;
+}
+
 // Closest hit (ANYHIT false) or occlusion query (ANYHIT true) on the library's
 // BVH.  Closest hit: returns the primitive and t like traceKdReference; hits
 // beyond tLimit are of no interest.  Occlusion: returns 0 as soon as any hit
 // satisfies the reference's occlusion test |(p + t d) - p|^2 < occDist2
 // (light.cpp:77-80,123-126; occDist2 < 0: any hit counts, light.cpp:21), else
 // RT_PRIM_NONE.
-//
-// The box tests only decide which subtrees are skipped, never a result, so they
-// run in binary32 with every plane distance widened by a bound of its rounding
-// error (entry distances are lower bounds, exit distances upper bounds).
 template <bool ANYHIT, bool STATS>
 __device__ int traceBvh(const DevScene& S, const V3& p, const V3& d, int rayType, double tLimit,
                         double occDist2, double& tOut, TraceCounters& cnt) {
   tOut = 0.0;
   if (!S.bvh_valid) return RT_PRIM_NONE;
   if (anynan(d) || anynan(p)) {
-    // A refraction past the critical angle leaves a NaN direction
-    // (RayTracer.cpp:193-199).  No comparison on a NaN orders anything, so no
-    // box can be culled; the reference's scan over Scene::objects
-    // (scene.cpp:144-153) then accepts the first object whose tests all fall
-    // through, and no triangle (trimesh.cpp:91-208 ends in range checks).
-    bool have = false;
-    double bt = 0.0;
-    int bp = RT_PRIM_NONE;
-    for (int j = 0; j < S.n_objects; j++) {
-      const RtObject& o = S.objects[j];
-      if (o.kind == RT_OBJ_TRIMESH) continue;
-      double t;
-      V3 N;
-      if (STATS) cnt.prims++;
-      if (objectIntersect<false>(o, p, d, t, N) && (!have || t < bt)) { have = true; bt = t; bp = j; }
-    }
+    double bt;
+    const int bp = bvhScanNaN<STATS>(S, p, d, bt, cnt);
     if (!ANYHIT) { tOut = bt; return bp; }
-    if (have) {
+    if (bp != RT_PRIM_NONE) {
       const V3 Qh = p + (bt * d);
       if (occDist2 < 0.0 || length2(Qh - p) < occDist2) { tOut = bt; return 0; }
     }
@@ -610,20 +775,8 @@ __device__ int traceBvh(const DevScene& S, const V3& p, const V3& d, int rayType
     double t0, t1;
     if (!boxIntersect(S.bvh_bb_min, S.bvh_bb_max, p, d, t0, t1)) return RT_PRIM_NONE;
   }
-  const bool cullBack = S.cull && rayType != RT_RAY_REFRACTION;
-  const V3 inv(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
-  // a direction component this small leaves the slab arithmetic; its axis gets
-  // an inside / outside test of the origin instead (see below)
-  const bool zx = !(fabs(d.x) >= 1.0e-30), zy = !(fabs(d.y) >= 1.0e-30), zz = !(fabs(d.z) >= 1.0e-30);
-  const bool zeroAny = zx | zy | zz;
-  const float ivx = (float)inv.x, ivy = (float)inv.y, ivz = (float)inv.z;
-  const bool negx = (d.x < 0.0) & !zx, negy = (d.y < 0.0) & !zy, negz = (d.z < 0.0) & !zz;
-  // object-space ray of every identity-transform mesh (Geometry::intersect,
-  // scene.cpp:17-20): position is unchanged, direction is ((p+d)-p) renormalised
-  const V3 dirI = (p + d) - p;
-  const double lenI = length(dirI);
-  const V3 ldI(dirI.x / lenI, dirI.y / lenI, dirI.z / lenI);
-
+  BvhRay r;
+  bvhRaySetup(S, p, d, rayType, r);
   bool haveOne = false;
   double bestT = tLimit;   // doubles as the far cull bound until a hit exists
   float bestTf = roundUpF(bestT);
@@ -634,65 +787,10 @@ __device__ int traceBvh(const DevScene& S, const V3& p, const V3& d, int rayType
   const float kInf = __int_as_float(0x7f800000);
   for (;;) {
     if (ref >= 0) {
-      const uint4* np = reinterpret_cast<const uint4*>(S.bvh + ref);
-      const uint4 w0 = np[0], w1 = np[1], w2 = np[2];
-      const uint2 w3 = *reinterpret_cast<const uint2*>(np + 3);
       if (STATS) cnt.nodes++;
-      const float ox = __uint_as_float(w0.x), oy = __uint_as_float(w0.y), oz = __uint_as_float(w0.z);
-      const int ex = (int)(int8_t)(w0.w & 255u), ey = (int)(int8_t)((w0.w >> 8) & 255u),
-                ez = (int)(int8_t)((w0.w >> 16) & 255u);
-      int kid[4] = {(int)w1.x, (int)w1.y, (int)w1.z, (int)w1.w};
       float tn[4];
-      // A = (origin - p) / d, B = 2^exp / d: plane q lies at distance A + q * B
-      const double ax = ((double)ox - p.x) * inv.x, ay = ((double)oy - p.y) * inv.y, az = ((double)oz - p.z) * inv.z;
-      float bx = ivx * pow2f(ex), by = ivy * pow2f(ey), bz = ivz * pow2f(ez);
-      const float afx = (float)ax, afy = (float)ay, afz = (float)az;
-      // rounding of A, of B and of the fused multiply-add: < 2^-23 (|A| + 255 |B|)
-      const float errx = 0x1p-22f * fmaf(255.0f, fabsf(bx), fabsf(afx));
-      const float erry = 0x1p-22f * fmaf(255.0f, fabsf(by), fabsf(afy));
-      const float errz = 0x1p-22f * fmaf(255.0f, fabsf(bz), fabsf(afz));
-      float a0x = afx - errx, a1x = afx + errx;
-      float a0y = afy - erry, a1y = afy + erry;
-      float a0z = afz - errz, a1z = afz + errz;
-      if (zeroAny) {
-        // The ray runs parallel to the slabs of this axis: with u = the origin in
-        // grid units, K (q_lo - u) and K (q_hi - u) for a huge K put the entry at
-        // -huge and the exit at +huge when the origin lies between the planes and
-        // the entry at +huge or the exit at -huge when it does not.
-        const float K = 0x1p40f;
-        if (zx) {
-          const float u = fminf(fmaxf((float)((p.x - (double)ox) * pow2i(-ex)), -1.0e9f), 1.0e9f);
-          const float m = fmaf(fabsf(u), 0x1p-21f, 0x1p-20f);
-          bx = K; a0x = -K * (u + m); a1x = -K * (u - m);
-        }
-        if (zy) {
-          const float u = fminf(fmaxf((float)((p.y - (double)oy) * pow2i(-ey)), -1.0e9f), 1.0e9f);
-          const float m = fmaf(fabsf(u), 0x1p-21f, 0x1p-20f);
-          by = K; a0y = -K * (u + m); a1y = -K * (u - m);
-        }
-        if (zz) {
-          const float u = fminf(fmaxf((float)((p.z - (double)oz) * pow2i(-ez)), -1.0e9f), 1.0e9f);
-          const float m = fmaf(fabsf(u), 0x1p-21f, 0x1p-20f);
-          bz = K; a0z = -K * (u + m); a1z = -K * (u - m);
-        }
-      }
-      // entry / exit plane words by the sign of the direction
-      const uint32_t q0x = negx ? w2.w : w2.x, q1x = negx ? w2.x : w2.w;
-      const uint32_t q0y = negy ? w3.x : w2.y, q1y = negy ? w2.y : w3.x;
-      const uint32_t q0z = negz ? w3.y : w2.z, q1z = negz ? w2.z : w3.y;
-#pragma unroll
-      for (int c = 0; c < 4; c += 2) {
-        const rt_f2 nx = slab2(q0x, c, bx, a0x), fx = slab2(q1x, c, bx, a1x);
-        const rt_f2 ny = slab2(q0y, c, by, a0y), fy = slab2(q1y, c, by, a1y);
-        const rt_f2 nz = slab2(q0z, c, bz, a0z), fz = slab2(q1z, c, bz, a1z);
-        const float tnear0 = fmaxf(fmaxf(nx.x, ny.x), nz.x), tnear1 = fmaxf(fmaxf(nx.y, ny.y), nz.y);
-        const float tfar0 = fminf(fminf(fminf(fx.x, fy.x), fz.x), bestTf);
-        const float tfar1 = fminf(fminf(fminf(fx.y, fy.y), fz.y), bestTf);
-        const bool h0 = (kid[c] != RT_BVH_EMPTY) & (tnear0 <= tfar0) & (tfar0 >= 0.0f);
-        const bool h1 = (kid[c + 1] != RT_BVH_EMPTY) & (tnear1 <= tfar1) & (tfar1 >= 0.0f);
-        tn[c] = h0 ? tnear0 : kInf;
-        tn[c + 1] = h1 ? tnear1 : kInf;
-      }
+      int kid[4];
+      bvhNodeSlabs(S, p, r, ref, bestTf, tn, kid);
       if (ANYHIT) {
         // Every overlapped subtree has to be searched unless an occluder turns
         // up, so only the descent wants an order: nearest child next, the
@@ -710,16 +808,7 @@ __device__ int traceBvh(const DevScene& S, const V3& p, const V3& d, int rayType
         }
         if (tb < kInf) { ref = kb; continue; }
       } else {
-        // ascending sorting network on (tn, kid): (0,1)(2,3)(0,2)(1,3)(1,2)
-#define RT_CSWAP(i, j)                                                       \
-        {                                                                    \
-          const bool sw = tn[j] < tn[i];                                     \
-          const float tlo = sw ? tn[j] : tn[i], thi = sw ? tn[i] : tn[j];    \
-          const int klo = sw ? kid[j] : kid[i], khi = sw ? kid[i] : kid[j];  \
-          tn[i] = tlo; tn[j] = thi; kid[i] = klo; kid[j] = khi;              \
-        }
-        RT_CSWAP(0, 1) RT_CSWAP(2, 3) RT_CSWAP(0, 2) RT_CSWAP(1, 3) RT_CSWAP(1, 2)
-#undef RT_CSWAP
+        bvhSort4(tn, kid);
         if (tn[0] < kInf) {
           // farthest first onto the stack, the nearest child is visited next
           if (tn[3] < kInf && sp < RT_BVH_STACK) { stack[sp].ref = kid[3]; stack[sp].tn = tn[3]; sp++; }
@@ -730,45 +819,10 @@ __device__ int traceBvh(const DevScene& S, const V3& p, const V3& d, int rayType
         }
       }
     } else {
-      const int x = ~ref;
-      if (x & RT_BVH_OBJECT_BIT) {
-        const int oi = x & 0x3fffffff;
-        double t;
-        V3 N;
-        if (STATS) cnt.prims++;
-        if (objectIntersect<false>(S.objects[oi], p, d, t, N)) {
-          if (ANYHIT) {
-            const V3 Qh = p + (t * d);
-            if (occDist2 < 0.0 || length2(Qh - p) < occDist2) { tOut = t; return 0; }
-          } else if (!haveOne || t < bestT) {
-            haveOne = true; bestT = t; bestPrim = oi;
-            bestTf = roundUpF(bestT);
-          }
-        }
-      } else {
-        const int first = x >> 3, count = (x & 7) + 1;
-        for (int k = 0; k < count; k++) {
-          const DevTri& T = S.bvhTris[first + k];
-          if (STATS) cnt.prims++;
-          double rt, tw;
-          bool hit;
-          if (T.axes & 16) {
-            hit = triTest<true>(T, p, ldI, cullBack, rt, nullptr);
-            tw = rt / lenI;
-          } else {
-            const LocalRay lr = toLocal(S.objects[T.owner].inverse, p, d);
-            hit = triTest<true>(T, lr.p, lr.d, cullBack, rt, nullptr);
-            tw = rt / lr.len;
-          }
-          if (!hit) continue;
-          if (ANYHIT) {
-            const V3 Qh = p + (tw * d);
-            if (occDist2 < 0.0 || length2(Qh - p) < occDist2) { tOut = tw; return 0; }
-          } else if (!haveOne || tw < bestT) {
-            haveOne = true; bestT = tw; bestPrim = RT_PRIM_FACE | T.face;
-            bestTf = roundUpF(bestT);
-          }
-        }
+      double tHit;
+      if (bvhLeaf<ANYHIT, STATS>(S, p, d, r, ref, occDist2, haveOne, bestT, bestTf, bestPrim, tHit, cnt)) {
+        tOut = tHit;
+        return 0;
       }
     }
     // pop the next subtree that can still contain a closer hit
