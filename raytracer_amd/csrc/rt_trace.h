@@ -781,8 +781,23 @@ __device__ int traceBvh(const DevScene& S, const V3& p, const V3& d, int rayType
   double bestT = tLimit;   // doubles as the far cull bound until a hit exists
   float bestTf = roundUpF(bestT);
   int bestPrim = RT_PRIM_NONE;
+  // The newest stack entry stays in registers (topRef / topTn), the rest in
+  // scratch memory: a pop then hands out the register entry at once and the
+  // load that refills it overlaps the work on the popped subtree.
   BvhEntry stack[RT_BVH_STACK];
   int sp = 0;
+  int topRef = RT_BVH_EMPTY;
+  float topTn = 0.0f;
+#define RT_BVH_PUSH(R, T)                                                          \
+  {                                                                                \
+    if (topRef != RT_BVH_EMPTY && sp < RT_BVH_STACK) {                             \
+      stack[sp].ref = topRef;                                                      \
+      if (!ANYHIT) stack[sp].tn = topTn;                                           \
+      sp++;                                                                        \
+    }                                                                              \
+    topRef = (R);                                                                  \
+    topTn = (T);                                                                   \
+  }
   int ref = 0;
   const float kInf = __int_as_float(0x7f800000);
   for (;;) {
@@ -804,16 +819,16 @@ __device__ int traceBvh(const DevScene& S, const V3& p, const V3& d, int rayType
           const int ko = nearer ? kb : kid[c];
           tb = nearer ? tn[c] : tb;
           kb = nearer ? kid[c] : kb;
-          if (to < kInf && sp < RT_BVH_STACK) { stack[sp].ref = ko; sp++; }
+          if (to < kInf) RT_BVH_PUSH(ko, 0.0f)
         }
         if (tb < kInf) { ref = kb; continue; }
       } else {
         bvhSort4(tn, kid);
         if (tn[0] < kInf) {
           // farthest first onto the stack, the nearest child is visited next
-          if (tn[3] < kInf && sp < RT_BVH_STACK) { stack[sp].ref = kid[3]; stack[sp].tn = tn[3]; sp++; }
-          if (tn[2] < kInf && sp < RT_BVH_STACK) { stack[sp].ref = kid[2]; stack[sp].tn = tn[2]; sp++; }
-          if (tn[1] < kInf && sp < RT_BVH_STACK) { stack[sp].ref = kid[1]; stack[sp].tn = tn[1]; sp++; }
+          if (tn[3] < kInf) RT_BVH_PUSH(kid[3], tn[3])
+          if (tn[2] < kInf) RT_BVH_PUSH(kid[2], tn[2])
+          if (tn[1] < kInf) RT_BVH_PUSH(kid[1], tn[1])
           ref = kid[0];
           continue;
         }
@@ -826,18 +841,22 @@ __device__ int traceBvh(const DevScene& S, const V3& p, const V3& d, int rayType
       }
     }
     // pop the next subtree that can still contain a closer hit
-    if (ANYHIT) {
-      if (sp == 0) break;
-      ref = stack[--sp].ref;
-    } else {
-      bool found = false;
-      while (sp > 0) {
+    bool found = false;
+    while (topRef != RT_BVH_EMPTY) {
+      const int candRef = topRef;
+      const float candTn = topTn;
+      if (sp > 0) {
         --sp;
-        if ((double)stack[sp].tn <= bestT) { ref = stack[sp].ref; found = true; break; }
+        topRef = stack[sp].ref;
+        if (!ANYHIT) topTn = stack[sp].tn;
+      } else {
+        topRef = RT_BVH_EMPTY;
       }
-      if (!found) break;
+      if (ANYHIT || (double)candTn <= bestT) { ref = candRef; found = true; break; }
     }
+    if (!found) break;
   }
+#undef RT_BVH_PUSH
   tOut = haveOne ? bestT : 0.0;
   return bestPrim;
 }
