@@ -119,20 +119,29 @@ __device__ __forceinline__ bool slotToPixel(const FrameMap& fm, long long slot, 
   return x < fm.width && y < fm.height;
 }
 
-// Camera::rayThrough for every sample of the batch (camera.cpp:20-31) at the
-// coordinates of tracePixel / tracePixelAntiAlias (RayTracer.cpp:51-52,84-92).
-__global__ void __launch_bounds__(kBlock)
-k_raygen(DevScene S, FrameMap fm, long long firstPixelSlot, int nSamples, Pool P) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= nSamples) return;
-  const long long slot = firstPixelSlot + i / fm.ns;
+// Where the rays of a level come from: the queue written by k_shade, or, for
+// level 0, the camera -- primary rays are generated where they are needed
+// instead of being written to and read from memory (every kernel that asks gets
+// the same bits, the function is deterministic).
+struct RaySrc {
+  const double* p;
+  const double* d;
+  const int* type;
+  size_t stride;
+  int primary;            // 1: level 0
+  FrameMap fm;
+  long long firstSlot;    // pixel slot of sample 0 of the batch
+};
+
+// Camera::rayThrough (camera.cpp:20-31) at the coordinates of tracePixel /
+// tracePixelAntiAlias (RayTracer.cpp:51-52,84-92) for sample i of the batch.
+// Returns the ray type, -1 for a sample of a pixel slot outside the frame.
+__device__ __forceinline__ int primaryRay(const DevScene& S, const FrameMap& fm, long long firstSlot, int i,
+                                          V3& p, V3& dir) {
+  const long long slot = firstSlot + i / fm.ns;
   const int k = i % fm.ns;
   int px, py, tk, lx, ly;
-  const bool active = slotToPixel(fm, slot, px, py, tk, lx, ly);
-  if (!active) {
-    P.rayType[0][i] = -1;
-    return;
-  }
+  if (!slotToPixel(fm, slot, px, py, tk, lx, ly)) return -1;
   double x = double(px) / double(fm.width);
   double y = double(py) / double(fm.height);
   if (fm.aaN > 0) {
@@ -146,10 +155,20 @@ k_raygen(DevScene S, FrameMap fm, long long firstPixelSlot, int nSamples, Pool P
   }
   x -= 0.5;
   y -= 0.5;
-  const V3 dir = normalized(V3(S.look) + x * V3(S.u) + y * V3(S.v));
-  storeV3(P.rayP[0], P.cap, i, V3(S.eye));
-  storeV3(P.rayD[0], P.cap, i, dir);
-  P.rayType[0][i] = RT_RAY_VISIBILITY;
+  dir = normalized(V3(S.look) + x * V3(S.u) + y * V3(S.v));
+  p = V3(S.eye);
+  return RT_RAY_VISIBILITY;
+}
+
+// Ray i of the level; returns its type (< 0: no ray in this slot).
+__device__ __forceinline__ int rayOf(const DevScene& S, const RaySrc& R, int i, V3& p, V3& d) {
+  if (R.primary) return primaryRay(S, R.fm, R.firstSlot, i, p, d);
+  const int type = R.type[i];
+  if (type >= 0) {
+    p = loadV3(R.p, R.stride, i);
+    d = loadV3(R.d, R.stride, i);
+  }
+  return type;
 }
 
 __device__ __forceinline__ void flushCounters(const TraceCounters& c, Counters* g, bool shadow) {
@@ -178,16 +197,15 @@ __device__ __forceinline__ void flushCounters(const TraceCounters& c, Counters* 
 // wavefront's lanes out of phase between node and leaf work.)
 template <bool FAST, bool STATS>
 __global__ void __launch_bounds__(kBlock) RT_TRACE_ATTR
-k_trace(DevScene S, int n, const double* rayP, const double* rayD, const int* rayType, size_t stride,
-        double* hitT, int* hitPrim, Counters* counters) {
+k_trace(DevScene S, int n, RaySrc R, double* hitT, int* hitPrim, Counters* counters) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   TraceCounters tc{0, 0};
   if (i < n) {
-    const int type = rayType[i];
+    V3 p, d;
+    const int type = rayOf(S, R, i, p, d);
     int prim = RT_PRIM_NONE;
     double t = 0.0;
     if (type >= 0) {
-      const V3 p = loadV3(rayP, stride, i), d = loadV3(rayD, stride, i);
       if (FAST) prim = traceBvh<false, STATS>(S, p, d, type, 1.0e308, -1.0, t, tc);
       else prim = traceKdReference<STATS>(S, p, d, type, t, tc);
     }
@@ -255,7 +273,7 @@ __device__ __forceinline__ unsigned int tileSlot(const TileScan& ts, int cls, in
 
 // Misses take the background (RayTracer.cpp:213-224); hits become shade points.
 __global__ void __launch_bounds__(kBlock)
-k_surface(DevScene S, int n, int items, int par, size_t rayOff, size_t spOff, int level, int useCube,
+k_surface(DevScene S, int n, int items, RaySrc R, size_t rayOff, size_t spOff, int level, int useCube,
           int filterWidth, Pool P) {
   __shared__ TileScan ts;
   __shared__ unsigned int litCount;
@@ -264,7 +282,7 @@ k_surface(DevScene S, int n, int items, int par, size_t rayOff, size_t spOff, in
   unsigned int hitMask = 0;
   for (int k = 0; k < items; k++) {
     const int i = tileBase + k * kBlock + threadIdx.x;
-    const bool hit = i < n && P.rayType[par][i] >= 0 && P.hitPrim[i] != RT_PRIM_NONE;
+    const bool hit = i < n && P.hitPrim[i] != RT_PRIM_NONE;   // k_trace leaves none in an empty slot
     hitMask |= (hit ? 1u : 0u) << k;
     tileCount(ts, 0, k, hit);
   }
@@ -276,10 +294,12 @@ k_surface(DevScene S, int n, int items, int par, size_t rayOff, size_t spOff, in
     const bool isHit = (hitMask >> k) & 1u;
     const unsigned int s = tileSlot(ts, 0, k, isHit);
     if (i >= n) continue;
-    const int type = P.rayType[par][i];
     if (!isHit) {
       V3 bg(0.0, 0.0, 0.0);
-      if (type >= 0 && useCube) bg = cubeColor(S, loadV3(P.rayD[par], P.cap, i), filterWidth);
+      if (useCube) {
+        V3 p, d;
+        if (rayOf(S, R, i, p, d) >= 0) bg = cubeColor(S, d, filterWidth);
+      }
       storeV3(P.rayI, P.cap, rayOff + i, bg);
       if (level == 0) P.primaryId[i] = 0;
       continue;
@@ -289,7 +309,8 @@ k_surface(DevScene S, int n, int items, int par, size_t rayOff, size_t spOff, in
       continue;
     }
     const int prim = P.hitPrim[i];
-    const V3 p = loadV3(P.rayP[par], P.cap, i), d = loadV3(P.rayD[par], P.cap, i);
+    V3 p, d;
+    const int type = rayOf(S, R, i, p, d);
     const double t = P.hitT[i];
     const size_t g = spOff + s;
     Surface sf;
@@ -441,17 +462,11 @@ k_shadow(DevScene S, long long nMax, size_t spOff, Pool P) {
   if (STATS) flushCounters(tc, P.counters, true);
 }
 
-// One thread per shade point: Material::shade (material.cpp:41-75) -- the
-// emissive + ambient base, then per light in scene order the attenuation from
-// its shadow query and the diffuse and specular terms, added in the
-// reference's order.
-__global__ void __launch_bounds__(kBlock)
-k_lights(DevScene S, int nMax, size_t spOff, Pool P) {
-  const int s = blockIdx.x * blockDim.x + threadIdx.x;
-  const unsigned int nsp = P.counters->nsp;
-  if (s >= nMax || (unsigned int)s >= nsp) return;
-  const size_t g = spOff + s;
-  const unsigned int mw = (unsigned int)P.spMat[g];
+// Material::shade of shade point s (material.cpp:41-75): the emissive + ambient
+// base, then per light in scene order the attenuation from its shadow query and
+// the diffuse and specular terms, added in the reference's order.
+__device__ __forceinline__ void shadePoint(const DevScene& S, const Pool& P, int s, size_t g, unsigned int mw,
+                                           const V3& Q, const V3& N) {
   const bool interp = (mw & RT_SPM_INTERP) != 0;
   if (!(mw & RT_SPM_LIT)) {
     // an interpolated material's base is already in spShade (k_surface)
@@ -473,7 +488,6 @@ k_lights(DevScene S, int nMax, size_t spOff, Pool P) {
     I = V3(dm.base);
   }
   const bool hasKd = !iszero(kd), hasKs = !iszero(ks);
-  const V3 Q = loadV3(P.spQ, P.cap, s), N = loadV3(P.spN, P.cap, s);
   for (int li = 0; li < S.n_lights; li++) {
     const size_t o = (size_t)li * P.cap + s;
     const int sp = P.shPrim[o];
@@ -493,10 +507,21 @@ k_lights(DevScene S, int nMax, size_t spOff, Pool P) {
   storeV3(P.spShade, P.cap, g, I);
 }
 
+// One thread per shade point: its colour.  (Folding this into k_shade's first
+// pass was measured slower: a thread there walks up to 16 points one after the
+// other, and pow / acos want the parallelism of a dense launch.)
+__global__ void __launch_bounds__(kBlock)
+k_lights(DevScene S, int nMax, size_t spOff, Pool P) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= nMax || (unsigned int)s >= P.counters->nsp) return;
+  const size_t g = spOff + s;
+  shadePoint(S, P, s, g, (unsigned int)P.spMat[g], loadV3(P.spQ, P.cap, s), loadV3(P.spN, P.cap, s));
+}
+
 // The secondary rays of RayTracer::traceRay (RayTracer.cpp:152-201).  Reflected rays of a tile are
 // queued before its refracted rays.
 __global__ void __launch_bounds__(kBlock)
-k_shade(DevScene S, int nMax, int items, int par, size_t spOff, size_t rayOff, size_t nextRayOff,
+k_shade(DevScene S, int nMax, int items, int par, RaySrc R, size_t spOff, size_t rayOff, size_t nextRayOff,
         int depthLeft, Pool P) {
   __shared__ TileScan ts;
   const unsigned int nsp = min((unsigned int)nMax, P.counters->nsp);
@@ -515,7 +540,8 @@ k_shade(DevScene S, int nMax, int items, int par, size_t spOff, size_t rayOff, s
       if (depthLeft > 0) {
         wantRefl = interp ? !iszero(loadV3(P.spKr, P.cap, g)) : (dm->flags & RT_MATF_KR) != 0;
         if (interp ? !iszero(loadV3(P.spKt, P.cap, g)) : (dm->flags & RT_MATF_KT) != 0) {
-          const V3 d = loadV3(P.rayD[par], P.cap, (size_t)P.spRayGlobal[g] - rayOff);
+          V3 p, d;
+          rayOf(S, R, (int)((size_t)P.spRayGlobal[g] - rayOff), p, d);
           const double cosineAngle = acos(dot(loadV3(P.spN, P.cap, s), d)) * 180 / M_PI;
           wantRefr = cosineAngle < 360;  // RayTracer.cpp:173,195: false only for a NaN angle
         }
@@ -547,7 +573,8 @@ k_shade(DevScene S, int nMax, int items, int par, size_t spOff, size_t rayOff, s
     const size_t g = spOff + s;
     int childRefl = -1, childRefr = -1;
     if (wantRefl || wantRefr) {
-      const V3 d = loadV3(P.rayD[par], P.cap, (size_t)P.spRayGlobal[g] - rayOff);
+      V3 p, d;
+      rayOf(S, R, (int)((size_t)P.spRayGlobal[g] - rayOff), p, d);
       const V3 N = loadV3(P.spN, P.cap, s);
       const V3 Q = loadV3(P.spQ, P.cap, s);
       const V3 minusD = -1 * d;
@@ -959,14 +986,13 @@ struct RenderCtx {
   const long long* tileOffDev;
   RtStats stats;
   bool fast, wantStats;
-  double growthSeen = 0.0;
+  double usedSlots = 0.0, usedSamples = 0.0;   // pool slots the frame's batches needed, for their samples
 };
 
 template <bool FAST, bool STATS>
-void launchTrace(RtScene* sc, int n, int par) {
+void launchTrace(RtScene* sc, int n, const RaySrc& R) {
   Pool& P = sc->pool;
-  k_trace<FAST, STATS><<<gridFor(n), kBlock, 0, sc->stream>>>(
-      sc->dev, n, P.rayP[par], P.rayD[par], P.rayType[par], P.cap, P.hitT, P.hitPrim, P.counters);
+  k_trace<FAST, STATS><<<gridFor(n), kBlock, 0, sc->stream>>>(sc->dev, n, R, P.hitT, P.hitPrim, P.counters);
 }
 template <bool FAST, bool STATS>
 void launchShadow(RtScene* sc, long long nMax, size_t spOff) {
@@ -1004,18 +1030,22 @@ int renderBatch(RenderCtx& cx, long long first, int count, long long* slotsUsed)
   int n = (int)nSamples, par = 0;
   size_t rayOff = 0, spOff = 0;
   unsigned long long litTotal = 0, nodes = 0, prims = 0, refl = 0, refr = 0, snodes = 0, sprims = 0;
-  k_raygen<<<gridFor(n), kBlock, 0, sc->stream>>>(sc->dev, cx.fm, first, n, P);
   for (int level = 0; level <= rp.depth && n > 0; level++) {
     HIP_TRY(hipMemsetAsync(P.counters, 0, sizeof(Counters), sc->stream));
+    RaySrc R;
+    R.p = P.rayP[par]; R.d = P.rayD[par]; R.type = P.rayType[par]; R.stride = P.cap;
+    R.primary = level == 0 ? 1 : 0;
+    R.fm = cx.fm;
+    R.firstSlot = first;
     const bool timed = timedBegin(sc);
-    if (cx.fast) { if (cx.wantStats) launchTrace<true, true>(sc, n, par); else launchTrace<true, false>(sc, n, par); }
-    else { if (cx.wantStats) launchTrace<false, true>(sc, n, par); else launchTrace<false, false>(sc, n, par); }
+    if (cx.fast) { if (cx.wantStats) launchTrace<true, true>(sc, n, R); else launchTrace<true, false>(sc, n, R); }
+    else { if (cx.wantStats) launchTrace<false, true>(sc, n, R); else launchTrace<false, false>(sc, n, R); }
     if (timed) timedEnd(sc, 0);
     cx.stats.trace_launches++;
     // entries per thread: enough tiles to fill the chip, few enough atomics
     const int items = std::min(kMaxItems, std::max(1, n / (kBlock * 2048)));
     const int tiles = (n + kBlock * items - 1) / (kBlock * items);
-    k_surface<<<tiles, kBlock, 0, sc->stream>>>(sc->dev, n, items, par, rayOff, spOff, level,
+    k_surface<<<tiles, kBlock, 0, sc->stream>>>(sc->dev, n, items, R, rayOff, spOff, level,
                                                      rp.use_cubemap && sc->dev.cube_w > 0,
                                                      rp.filter_width, P);
     const long long shadowThreads = (long long)n * sc->dev.n_lights;
@@ -1027,7 +1057,7 @@ int renderBatch(RenderCtx& cx, long long first, int count, long long* slotsUsed)
       cx.stats.lights_launches++;
     }
     k_lights<<<gridFor(n), kBlock, 0, sc->stream>>>(sc->dev, n, spOff, P);
-    k_shade<<<tiles, kBlock, 0, sc->stream>>>(sc->dev, n, items, par, spOff, rayOff, rayOff + n,
+    k_shade<<<tiles, kBlock, 0, sc->stream>>>(sc->dev, n, items, par, R, spOff, rayOff, rayOff + n,
                                               rp.depth - level, P);
     Counters c;
     HIP_TRY(hipMemcpyAsync(&c, P.counters, sizeof c, hipMemcpyDeviceToHost, sc->stream));
@@ -1105,7 +1135,8 @@ int renderRange(RenderCtx& cx, long long first, long long count) {
     const double seen = 1.15 * (double)used / ((double)c * cx.fm.ns) + 0.05;
     if (!sc->growthMeasured) { sc->growth = seen; sc->growthMeasured = true; }
     else sc->growth = std::max(sc->growth, seen);
-    cx.growthSeen = std::max(cx.growthSeen, seen);
+    cx.usedSlots += (double)used;
+    cx.usedSamples += (double)c * cx.fm.ns;
     b += c;
   }
   return RT_OK;
@@ -1577,7 +1608,8 @@ int rt_render(RtScene* sc, const RtRenderParams* rp, unsigned char* rgb8_out, in
     HIP_TRY(hipStreamSynchronize(sc->stream));
   }
   if (listDev) hipFree(listDev);
-  if (cx.growthSeen > 0.0) sc->growth = cx.growthSeen;
+  // the next frame starts from this frame's overall growth, not from its worst batch
+  if (cx.usedSamples > 0.0) sc->growth = 1.1 * cx.usedSlots / cx.usedSamples + 0.05;
 
   float ms = 0.f;
   HIP_TRY(hipEventElapsedTime(&ms, sc->evStart, sc->evStop));
