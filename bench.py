@@ -174,8 +174,8 @@ def main():
 
     # Untimed pass with device counters: tree nodes visited (V) and primitives
     # tested (T), split between the closest-hit kernel (k_trace: primary,
-    # reflection and refraction rays) and the shading kernel's shadow rays
-    # (k_lights).  Algorithmic bytes of a ray: node_bytes V + 128 T + 160 (node
+    # reflection and refraction rays) and the shadow-query kernel
+    # (k_shadow).  Algorithmic bytes of a ray: node_bytes V + 128 T + 160 (node
     # record: 64 B BVH node on the fast path, 16 B KD node on the reference path;
     # 128 B triangle record; an 80 B ray record written and read once through the
     # level queues).  The roofline entry is k_trace, the kernel with the largest
@@ -223,7 +223,7 @@ def main():
                 "note": "algorithmic bytes are served by L1/L2 (the tree is shared by neighbouring rays): "
                         "measured HBM traffic is a small fraction of them, the kernel is bound by FP64 "
                         "VALU issue and vector-memory latency, not by HBM",
-                "k_trace": kt, "k_lights": kl}
+                "k_trace": kt, "k_shadow": kl}
 
     if rank == 0:
         if args.out:

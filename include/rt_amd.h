@@ -193,7 +193,7 @@ typedef struct RtStats {
   double ms_trace;           /* HIP-event time of the closest-hit launches (k_trace) */
   int    trace_launches;     /* number of those launches */
   int    batches;
-  double ms_lights;          /* HIP-event time of the shading + shadow-ray launches (k_lights) */
+  double ms_lights;          /* HIP-event time of the shadow-query launches (k_shadow) */
   int    lights_launches;
   int    _pad;
   unsigned long long shadow_nodes_visited, shadow_prims_tested;  /* shadow rays' share of the two totals */

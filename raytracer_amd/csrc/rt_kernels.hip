@@ -1286,6 +1286,26 @@ int rt_scene_create(const RtSceneDesc* d, RtScene** out) {
     }
     DevTri* p; HIP_TRY(upload(tris.data(), tris.size(), &p)); keep(p); D.tris = p;
     int* q; HIP_TRY(upload(ids.data(), ids.size(), &q)); keep(q); D.face_ids = q;
+    // the three vertex normals of a face side by side: one 72-byte gather per
+    // hit instead of an index triple and three scattered normals
+    D.face_normals = nullptr;
+    if (d->smooth_shading && d->vnormals) {
+      bool any = false;
+      for (int mi = 0; mi < d->n_meshes; mi++) any = any || d->meshes[mi].has_vertex_normals;
+      if (any) {
+        std::vector<double> fn(9 * (size_t)d->n_faces, 0.0);
+        for (int mi = 0; mi < d->n_meshes; mi++) {
+          const RtMesh& M = d->meshes[mi];
+          if (!M.has_vertex_normals) continue;
+          for (int f = 0; f < M.n_faces; f++) {
+            const size_t fi = (size_t)M.first_face + f;
+            for (int k = 0; k < 3; k++)
+              for (int a = 0; a < 3; a++) fn[9 * fi + 3 * k + a] = d->vnormals[3 * (size_t)ids[3 * fi + k] + a];
+          }
+        }
+        double* fp; HIP_TRY(upload(fn.data(), fn.size(), &fp)); keep(fp); D.face_normals = fp;
+      }
+    }
 
     // ---- the library's own BVH over world-space triangle and object boxes
     if ((size_t)d->n_faces >= (1u << 27)) return fail(RT_ERR_UNSUPPORTED, "too many triangles for the BVH leaf encoding");

@@ -75,9 +75,8 @@ __device__ __forceinline__ void surfaceAt(const DevScene& S, int prim, const V3&
     if (!ktOnly) {
       V3 Nl;
       if (S.smooth && m.has_vertex_normals) {
-        const int* ids = S.face_ids + 3 * fi;
-        const V3 nA(S.vnormals + 3 * (size_t)ids[0]), nB(S.vnormals + 3 * (size_t)ids[1]),
-            nC(S.vnormals + 3 * (size_t)ids[2]);
+        const double* fn = S.face_normals + 9 * (size_t)fi;
+        const V3 nA(fn), nB(fn + 3), nC(fn + 6);
         Nl = (bary.x * nA) + (bary.y * nB) + (bary.z * nC);
       } else {
         Nl = V3(T.n);

@@ -85,6 +85,7 @@ struct DevScene {
   const RtMaterial* materials;
   const RtLight* lights;
   const double* vnormals;    // 3 per global vertex
+  const double* face_normals;  // 9 per face: the vertex normals of its corners (NULL: none / flat shading)
   const int* vmaterials;     // material index per global vertex
   const unsigned char* cube[6];
   int cube_w, cube_h;
