@@ -6,5 +6,5 @@ cd "$(dirname "$0")/.."
 var=$1; shift
 for v in "$@"; do
   echo "== $var=$v"
-  env $var=$v timeout -k 10 200 python bench.py --steps 4 --warmup 2 --cpu-seconds 0 ${BENCH_ARGS:-} 2>/dev/null | tail -1 | python -c "import sys,json; j=json.loads(sys.stdin.read()); print(j['value'], j['ms_per_step'], j["config"]["trace_ms_per_step"], j["config"]["lights_ms_per_step"], j['roofline']['nodes_per_ray'], j['roofline']['prims_per_ray'])" || exit 1
+  env $var=$v timeout -k 10 200 python bench.py --steps 4 --warmup 2 --cpu-seconds 0 ${BENCH_ARGS:-} 2>/dev/null | python tools/bench_line.py || exit 1
 done
