@@ -751,6 +751,10 @@ __device__ __forceinline__ bool bvhLeaf(const DevScene& S, const V3& p, const V3
   return false;
 }
 
+// (Measured and dropped: pushing the closest-hit children unsorted, +4 %
+// time; parking one leaf per lane so that lanes stay in the node loop together,
+// +14 %.)
+//
 // Closest hit (ANYHIT false) or occlusion query (ANYHIT true) on the library's
 // BVH.  Closest hit: returns the primitive and t like traceKdReference; hits
 // beyond tLimit are of no interest.  Occlusion: returns 0 as soon as any hit
