@@ -209,10 +209,14 @@ def main():
         kt = kernel_line(V - Vs, T - Ts, R - Rs, trace_ms, trace_n)
         kl = kernel_line(Vs, Ts, Rs, lights_ms, lights_n)
         traffic = None
+        profiled = {}
         tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.config)
         if os.path.exists(tpath) and args.scale == 1.0 and world == 1 and args.traversal == "fast":
             try:
-                traffic = json.load(open(tpath)).get("k_trace_hbm_bytes_per_launch")
+                tj = json.load(open(tpath))
+                traffic = tj.get("k_trace_hbm_bytes_per_launch")
+                profiled = {"valu_busy_profiled": tj.get("k_trace_valu_busy"),
+                            "lanes_active_profiled": tj.get("k_trace_lanes_active"), "profile": tj.get("source")}
             except Exception:
                 traffic = None
         roof = {"bound": "hbm",
@@ -221,9 +225,10 @@ def main():
                 "achieved": kt["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(kt["achieved"] / HBM_PEAK_GBS, 6), "traffic": traffic,
                 "note": "algorithmic bytes are served by L1/L2 (the tree is shared by neighbouring rays): "
-                        "measured HBM traffic is a small fraction of them, the kernel is bound by FP64 "
-                        "VALU issue and vector-memory latency, not by HBM",
+                        "measured HBM traffic is a small fraction of them, the kernel is bound by VALU "
+                        "issue (see valu_busy_profiled) and vector-memory latency, not by HBM",
                 "k_trace": kt, "k_shadow": kl}
+        roof.update(profiled)
 
     if rank == 0:
         if args.out:

@@ -79,7 +79,10 @@ def main():
         simd_quads = v["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0 / 4.0      # SIMD x quad-cycles the kernel was resident
         rd = 2.0 * fetch[k].get("FETCH_SIZE", 0.0) * 1024.0 / max(nf.get(k, 1), 1)
         wr = write[k].get("WRITE_SIZE", 0.0) * 1024.0 / max(nw.get(k, 1), 1)
-        traffic[k] = {"read_bytes_per_launch": round(rd), "write_bytes_per_launch": round(wr), "launches": ns[k]}
+        traffic[k] = {"read_bytes_per_launch": round(rd), "write_bytes_per_launch": round(wr), "launches": ns[k],
+                      "valu_busy": round(v["SQ_ACTIVE_INST_VALU"] / simd_quads, 3),
+                      "lanes_active": round(v["SQ_THREAD_CYCLES_VALU"] / max(v["SQ_ACTIVE_INST_VALU"], 1.0), 1),
+                      "waves_per_simd": round(wc / simd_quads, 2)}
         lines.append("| %s | %d | %.1f | %.1f | %.2f | %.0f %% | %.1f / 64 | %.0f %% / %.0f %% / %.0f %% |" % (
             k, ns[k], rd / 1e6, wr / 1e6, wc / simd_quads, 100.0 * v["SQ_ACTIVE_INST_VALU"] / simd_quads,
             v["SQ_THREAD_CYCLES_VALU"] / max(v["SQ_ACTIVE_INST_VALU"], 1.0),
@@ -89,6 +92,8 @@ def main():
     out = {"source": "profiles/%s_pmc_summary.md" % tag, "kernels": traffic}
     if kt:
         out["k_trace_hbm_bytes_per_launch"] = kt["read_bytes_per_launch"] + kt["write_bytes_per_launch"]
+        out["k_trace_valu_busy"] = kt["valu_busy"]
+        out["k_trace_lanes_active"] = kt["lanes_active"]
     json.dump(out, open(os.path.join(dst, "traffic_C4.json"), "w"), indent=1)
     print("\n".join(lines))
 
