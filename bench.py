@@ -234,7 +234,7 @@ def main():
         if args.out:
             host.write_bmp(args.out, frame.cpu().numpy())
         cpu = None
-        if args.cpu_seconds > 0:
+        if args.cpu_seconds > 0 and world == 1:   # the CPU leg belongs to the single-GPU line only
             cpu = cpu_baseline(hs, width, height, kw, args.cpu_seconds)
         value = total_rays / elapsed / 1e6
         out = {
