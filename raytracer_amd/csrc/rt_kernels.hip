@@ -238,28 +238,36 @@ __device__ __forceinline__ void tileCount(TileScan& ts, int cls, int k, bool fla
 }
 
 // Between the passes: exclusive scan of the counts (class 0 first, then class
-// 1), one atomicAdd of the total on *counter.  Returns the totals per class.
+// 1), one atomicAdd of the total on *counter.  Returns the totals per class (in
+// thread 0 only).  The first wavefront scans: lane l owns the counter of item
+// l / kWaves, wave l % kWaves (kMaxItems * kWaves = 64 counters per class).
 __device__ __forceinline__ void tileReserve(TileScan& ts, int items, int classes, unsigned int* counter,
                                             unsigned int& total0, unsigned int& total1) {
+  static_assert(kMaxItems * kWaves == 64, "one lane per counter");
   __syncthreads();
-  if (threadIdx.x == 0) {
-    unsigned int run = 0;
+  if (threadIdx.x < 64) {
+    const int lane = threadIdx.x;
+    const int k = lane / kWaves, w = lane % kWaves;
+    unsigned int run = 0, tot[2] = {0, 0};
     for (int c = 0; c < classes; c++) {
-      const unsigned int start = run;
-      for (int k = 0; k < items; k++)
-        for (int w = 0; w < kWaves; w++) {
-          const unsigned int v = ts.cnt[c][k][w];
-          ts.cnt[c][k][w] = run;
-          run += v;
-        }
-      ts.base[c] = run - start;   // class total, replaced by the global base below
+      const unsigned int v = (k < items) ? ts.cnt[c][k][w] : 0u;
+      unsigned int incl = v;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const unsigned int o = __shfl_up(incl, off);
+        if (lane >= off) incl += o;
+      }
+      if (k < items) ts.cnt[c][k][w] = run + incl - v;
+      tot[c] = __shfl(incl, 63);
+      run += tot[c];
     }
-    const unsigned int t0 = ts.base[0], t1 = (classes > 1) ? ts.base[1] : 0;
-    const unsigned int g = run ? atomicAdd(counter, run) : 0;
-    ts.base[0] = g;
-    ts.base[1] = g;
-    total0 = t0;
-    total1 = t1;
+    if (lane == 0) {
+      const unsigned int g = run ? atomicAdd(counter, run) : 0;
+      ts.base[0] = g;
+      ts.base[1] = g;
+      total0 = tot[0];
+      total1 = tot[1];
+    }
   }
   __syncthreads();
 }
