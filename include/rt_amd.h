@@ -234,6 +234,17 @@ int rt_unpack_tiles(const unsigned char* packed_dev, int bytes_per_pixel,
                     int width, int height, int tile_w, int tile_h,
                     int shard_index, int shard_count, unsigned char* frame_dev, void* hip_stream);
 
+/* Renders the listed pixels only: tracePixel (aa_mode RT_AA_NONE,
+ * src/RayTracer.cpp:45-62) or tracePixelAntiAlias with aa_samples x aa_samples
+ * jittered samples each (any other aa_mode, src/RayTracer.cpp:64-103).  This is
+ * the second pass of GraphicalUI::doAntiAliasing (src/ui/GraphicalUI.cpp:377-435)
+ * for a caller that holds the flagged pixels itself -- e.g. one rank of a
+ * multi-GPU frame that takes its share of them.  xy: n_pixels (x, y) pairs;
+ * rgb8_out: 3 bytes per listed pixel, in list order (both host memory).  Tile and
+ * shard fields of the parameters are ignored. */
+int rt_render_pixels(RtScene* scene, const RtRenderParams* params, int n_pixels, const int* xy,
+                     unsigned char* rgb8_out, RtStats* stats_out);
+
 /* Laplacian edge mask of GraphicalUI::applyFilter (ui/GraphicalUI.cpp:437-486)
  * on a host RGB8 frame; mask_out gets 255 / 0 per pixel. */
 int rt_edge_mask(const unsigned char* rgb8, int width, int height, int cutoff,

@@ -101,6 +101,8 @@ class RthOptions(C.Structure):
 RT_AMD_SYMBOLS = {
     "rt_scene_create": (C.c_int, [C.POINTER(RtSceneDesc), C.POINTER(C.c_void_p)]),
     "rt_scene_destroy": (None, [C.c_void_p]),
+    "rt_render_pixels": (C.c_int, [C.c_void_p, C.POINTER(RtRenderParams), C.c_int, C.c_void_p, C.c_void_p,
+                                  C.POINTER(RtStats)]),
     "rt_render": (C.c_int, [C.c_void_p, C.POINTER(RtRenderParams), C.c_void_p, C.c_void_p,
                             C.POINTER(RtStats)]),
     "rt_intersect_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_int, PD, PI, C.POINTER(RtHit)]),

@@ -89,6 +89,7 @@ struct FrameMap {           // pixel slot -> pixel, for tile-ordered rendering
   int tileW, tileH, tilesX;
   int shardIndex, shardCount;
   const int* pixelList;     // optional explicit (x,y) list (adaptive AA), else NULL
+  int listOutput;           // with pixelList: 1 = the output is indexed by list position, 0 = by frame position
   int ns;                   // samples per pixel
   int aaN;                  // n (ns = n*n) or 0
   const double* jitter;     // device copy, 2*ns values or NULL
@@ -694,7 +695,9 @@ k_resolve(FrameMap fm, long long firstPixelSlot, int nPixels, int ppb, Pool P, u
     col = V3(lds[0][r + ns - 1], lds[1][r + ns - 1], lds[2][r + ns - 1]);
   }
   size_t o;
-  if (tileOffset) {
+  if (fm.pixelList && fm.listOutput) {
+    o = (size_t)slot;
+  } else if (tileOffset) {
     const int t = fm.shardIndex + tk * fm.shardCount;
     const int tx = t % fm.tilesX;
     const int wt = min(fm.tileW, fm.width - tx * fm.tileW);
@@ -1164,6 +1167,42 @@ size_t workspaceBudgetBytes(size_t alreadyHeld) {
   return mb * 1024 * 1024;
 }
 
+// Sizes (and if needed reallocates) the ray pool for a frame of `slots` samples.
+int sizePool(RtScene* sc, const RtRenderParams* rp, long long slots) {
+  if (sc->growthDepth != rp->depth) {
+    // a chain of rays per bounce, a tree where surfaces also refract
+    sc->growth = (double)std::min<long long>((1ll << std::min(rp->depth + 1, 20)) - 1, 6);
+    sc->growthMeasured = false;
+    sc->growthDepth = rp->depth;
+  }
+  const bool interp = sc->dev.interp_materials != 0;
+  const bool opaque = sc->dev.opaque != 0;
+  const size_t perSlot = poolBytesPerSlot(sc->nLights, interp, opaque);
+  size_t cap = workspaceBudgetBytes(sc->pool.cap * poolBytesPerSlot((int)sc->poolLights, interp, opaque)) / perSlot;
+  const size_t want = (size_t)std::max<double>((double)slots * sc->growth * 1.1, 1 << 16);
+  cap = std::min(cap, want);
+  cap = std::min<size_t>(cap, 0x3fffffff);
+  if (rp->max_batch_samples > 0) cap = std::min<size_t>(cap, (size_t)rp->max_batch_samples * 8);
+  cap = std::max<size_t>(cap, 1 << 14);
+  if (sc->pool.cap < cap || sc->pool.cap > 4 * cap) return ensurePool(sc, cap);
+  return RT_OK;
+}
+
+// Device copy of the caller's jitter table (2 * ns doubles).
+int uploadJitter(RtScene* sc, const RtRenderParams* rp, int ns) {
+  if (ns <= 1 || !rp->jitter) return RT_OK;
+  const size_t need = 2 * (size_t)ns;
+  if (need > sc->jitterCap) {
+    if (sc->jitterDev) hipFree(sc->jitterDev);
+    sc->jitterDev = nullptr;
+    sc->jitterCap = 0;
+    HIP_TRY(hipMalloc((void**)&sc->jitterDev, need * sizeof(double)));
+    sc->jitterCap = need;
+  }
+  HIP_TRY(hipMemcpyAsync(sc->jitterDev, rp->jitter, need * sizeof(double), hipMemcpyHostToDevice, sc->stream));
+  return RT_OK;
+}
+
 }  // namespace
 
 // ================================================================== C-ABI
@@ -1497,28 +1536,9 @@ int rt_render(RtScene* sc, const RtRenderParams* rp, unsigned char* rgb8_out, in
   TileLayout TL = tileLayout(w, h, rp->tile_w, rp->tile_h, rp->shard_index, rp->shard_count);
   const int nsFull = (rp->aa_mode == RT_AA_NONE) ? 1 : rp->aa_samples * rp->aa_samples;
 
-  // ---- workspace
   {
-    if (sc->growthDepth != rp->depth) {
-      // a chain of rays per bounce, a tree where surfaces also refract
-      sc->growth = (double)std::min<long long>((1ll << std::min(rp->depth + 1, 20)) - 1, 6);
-      sc->growthMeasured = false;
-      sc->growthDepth = rp->depth;
-    }
-    const bool interp = sc->dev.interp_materials != 0;
-    const bool opaque = sc->dev.opaque != 0;
-    const size_t perSlot = poolBytesPerSlot(sc->nLights, interp, opaque);
-    size_t cap = workspaceBudgetBytes(sc->pool.cap * poolBytesPerSlot((int)sc->poolLights, interp, opaque)) / perSlot;
-    const long long slots = (long long)TL.nTiles * rp->tile_w * rp->tile_h * nsFull;
-    const size_t want = (size_t)std::max<double>((double)slots * sc->growth * 1.1, 1 << 16);
-    cap = std::min(cap, want);
-    cap = std::min<size_t>(cap, 0x3fffffff);
-    if (rp->max_batch_samples > 0) cap = std::min<size_t>(cap, (size_t)rp->max_batch_samples * 8);
-    cap = std::max<size_t>(cap, 1 << 14);
-    if (sc->pool.cap < cap || sc->pool.cap > 4 * cap) {
-      int rc = ensurePool(sc, cap);
-      if (rc != RT_OK) return rc;
-    }
+    const int rc = sizePool(sc, rp, (long long)TL.nTiles * rp->tile_w * rp->tile_h * nsFull);
+    if (rc != RT_OK) return rc;
   }
   if (TL.offsets.size() > sc->tileOffsetsCap) {
     if (sc->tileOffsets) hipFree(sc->tileOffsets);
@@ -1528,14 +1548,9 @@ int rt_render(RtScene* sc, const RtRenderParams* rp, unsigned char* rgb8_out, in
   if (!TL.offsets.empty())
     HIP_TRY(hipMemcpyAsync(sc->tileOffsets, TL.offsets.data(), TL.offsets.size() * sizeof(long long),
                            hipMemcpyHostToDevice, sc->stream));
-  if (nsFull > 1 && rp->jitter) {
-    const size_t need = 2 * (size_t)nsFull;
-    if (need > sc->jitterCap) {
-      if (sc->jitterDev) hipFree(sc->jitterDev);
-      HIP_TRY(hipMalloc((void**)&sc->jitterDev, need * sizeof(double)));
-      sc->jitterCap = need;
-    }
-    HIP_TRY(hipMemcpyAsync(sc->jitterDev, rp->jitter, need * sizeof(double), hipMemcpyHostToDevice, sc->stream));
+  {
+    const int rc = uploadJitter(sc, rp, nsFull);
+    if (rc != RT_OK) return rc;
   }
   if (!rp->out_is_device) {
     const size_t px = (size_t)w * h;
@@ -1565,6 +1580,7 @@ int rt_render(RtScene* sc, const RtRenderParams* rp, unsigned char* rgb8_out, in
   fm.tileW = rp->tile_w; fm.tileH = rp->tile_h; fm.tilesX = TL.tilesX;
   fm.shardIndex = rp->shard_index; fm.shardCount = rp->shard_count;
   fm.pixelList = nullptr;
+  fm.listOutput = 0;
   fm.ns = (rp->aa_mode == RT_AA_FULL) ? nsFull : 1;
   fm.aaN = (rp->aa_mode == RT_AA_FULL) ? rp->aa_samples : 0;
   fm.jitter = (rp->aa_mode != RT_AA_NONE && rp->jitter) ? sc->jitterDev : nullptr;
@@ -1652,6 +1668,81 @@ int rt_render(RtScene* sc, const RtRenderParams* rp, unsigned char* rgb8_out, in
   cx.stats.ms_lights = lightsMs;
   cx.stats.ms_total =
       std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  if (stats_out) *stats_out = cx.stats;
+  return RT_OK;
+}
+
+int rt_render_pixels(RtScene* sc, const RtRenderParams* rp, int n_pixels, const int* xy, unsigned char* rgb8_out,
+                     RtStats* stats_out) {
+  if (!sc || !rp || n_pixels < 0 || (n_pixels > 0 && (!xy || !rgb8_out))) return fail(RT_ERR_INVALID, "null argument");
+  if (rp->width <= 0 || rp->height <= 0 || rp->depth < 0) return fail(RT_ERR_INVALID, "bad frame size or depth");
+  if (rp->aa_mode != RT_AA_NONE && (rp->aa_samples < 1 || rp->aa_samples > 8))
+    return fail(RT_ERR_INVALID, "aa_samples must be 1..8");
+  if (rp->traversal != RT_TRAVERSE_REFERENCE && rp->traversal != RT_TRAVERSE_FAST)
+    return fail(RT_ERR_INVALID, "bad traversal mode");
+  for (int k = 0; k < n_pixels; k++)
+    if (xy[2 * k] < 0 || xy[2 * k] >= rp->width || xy[2 * k + 1] < 0 || xy[2 * k + 1] >= rp->height)
+      return fail(RT_ERR_INVALID, "listed pixel outside the frame");
+  const auto t0 = std::chrono::steady_clock::now();
+  HIP_TRY(hipSetDevice(sc->device));
+  RenderCtx cx;
+  cx.sc = sc;
+  cx.rp = rp;
+  std::memset(&cx.stats, 0, sizeof cx.stats);
+  if (n_pixels == 0) {
+    if (stats_out) *stats_out = cx.stats;
+    return RT_OK;
+  }
+  const int ns = (rp->aa_mode == RT_AA_NONE) ? 1 : rp->aa_samples * rp->aa_samples;
+  int rc = sizePool(sc, rp, (long long)n_pixels * ns);
+  if (rc != RT_OK) return rc;
+  rc = uploadJitter(sc, rp, ns);
+  if (rc != RT_OK) return rc;
+  int* listDev = nullptr;
+  unsigned char* outDev = nullptr;
+  HIP_TRY(hipMalloc((void**)&listDev, (size_t)n_pixels * 2 * sizeof(int)));
+  if (hipMalloc((void**)&outDev, (size_t)n_pixels * 3) != hipSuccess) {
+    hipFree(listDev);
+    return fail(RT_ERR_NOMEM, "cannot allocate the pixel list output");
+  }
+  auto cleanup = [&] { hipFree(listDev); hipFree(outDev); };
+  if (hipMemcpyAsync(listDev, xy, (size_t)n_pixels * 2 * sizeof(int), hipMemcpyHostToDevice, sc->stream) != hipSuccess) {
+    cleanup();
+    return fail(RT_ERR_DEVICE, "pixel list upload failed");
+  }
+  cx.fast = rp->traversal == RT_TRAVERSE_FAST;
+  cx.wantStats = rp->collect_stats != 0;
+  cx.rgbDev = outDev;
+  cx.hitDev = nullptr;
+  cx.tileOffDev = nullptr;
+  FrameMap& fm = cx.fm;
+  fm.width = rp->width; fm.height = rp->height;
+  fm.tileW = fm.tileH = 8; fm.tilesX = 1;
+  fm.shardIndex = 0; fm.shardCount = 1;
+  fm.pixelList = listDev;
+  fm.listOutput = 1;
+  fm.ns = ns;
+  fm.aaN = (rp->aa_mode == RT_AA_NONE) ? 0 : rp->aa_samples;
+  fm.jitter = (rp->aa_mode != RT_AA_NONE && rp->jitter) ? sc->jitterDev : nullptr;
+  sc->eventsUsed = 0;
+  hipEventRecord(sc->evStart, sc->stream);
+  rc = renderRange(cx, 0, n_pixels);
+  hipEventRecord(sc->evStop, sc->stream);
+  if (rc == RT_OK && hipMemcpyAsync(rgb8_out, outDev, (size_t)n_pixels * 3, hipMemcpyDeviceToHost, sc->stream) != hipSuccess)
+    rc = fail(RT_ERR_DEVICE, "pixel list download failed");
+  hipStreamSynchronize(sc->stream);
+  cleanup();
+  if (rc != RT_OK) return rc;
+  if (cx.usedSamples > 0.0) sc->growth = 1.1 * cx.usedSlots / cx.usedSamples + 0.05;
+  cx.stats.rays_primary = (unsigned long long)n_pixels * ns;
+  float ms = 0.f;
+  if (hipEventElapsedTime(&ms, sc->evStart, sc->evStop) == hipSuccess) cx.stats.ms_device = ms;
+  for (size_t e = 0; e + 1 < sc->eventsUsed; e += 2) {
+    float m = 0.f;
+    if (hipEventElapsedTime(&m, sc->events[e], sc->events[e + 1]) == hipSuccess)
+      (sc->eventKind[e / 2] ? cx.stats.ms_lights : cx.stats.ms_trace) += m;
+  }
+  cx.stats.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   if (stats_out) *stats_out = cx.stats;
   return RT_OK;
 }

@@ -89,6 +89,15 @@ class DeviceScene:
                                C.c_void_p(hit_dev_ptr) if hit_dev_ptr else None, C.byref(st)), "rt_render")
         return st
 
+    def render_pixels(self, params, xy):
+        """Renders the listed (x, y) pixels only; returns (rgb[n,3] uint8, RtStats)."""
+        xy = np.ascontiguousarray(xy, dtype=np.int32).reshape(-1, 2)
+        out = np.zeros((len(xy), 3), dtype=np.uint8)
+        st = abi.RtStats()
+        _check(lib().rt_render_pixels(self._h, C.byref(params), len(xy), xy.ctypes.data, out.ctypes.data,
+                                      C.byref(st)), "rt_render_pixels")
+        return out, st
+
     def intersect(self, rays_pd, types=None, traversal=abi.RT_TRAVERSE_REFERENCE):
         rays = np.ascontiguousarray(rays_pd, dtype=np.float64).reshape(-1, 6)
         n = len(rays)

@@ -63,3 +63,87 @@ def gather_packed(local_packed, world_size, rank, dst=0, force=False):
     bufs = [torch.empty_like(local_packed) for _ in range(world_size)] if rank == dst else None
     dist.gather(local_packed, gather_list=bufs, dst=dst)
     return bufs
+
+
+# ---- adaptive anti-aliasing over several shards --------------------------------
+# GraphicalUI::doAntiAliasing (src/ui/GraphicalUI.cpp:377-435) needs the whole
+# base image for its edge mask.  With the frame sharded: every rank renders its
+# tiles of the base image, ONE all-gather makes the base image complete on every
+# rank, every rank computes the same mask and re-renders its share of the
+# flagged pixels (every N-th one, which balances edges clustered in one part of
+# the screen), and one gather brings the re-rendered pixels to rank 0.
+
+def flagged_pixels(mask):
+    """(x, y) of the mask's 255 entries in the reference's loop order (rows outer)."""
+    ys, xs = np.nonzero(np.asarray(mask) == 255)
+    return np.stack([xs, ys], axis=1).astype(np.int32)
+
+
+def flagged_share(xy, shard_index, shard_count):
+    """This shard's part of the flagged list: entries shard_index, +shard_count, ..."""
+    return np.ascontiguousarray(xy[shard_index::shard_count])
+
+
+def patch_pixels(frame, xy, rgb):
+    """Overwrites the listed pixels of an (H, W, 3) frame (row 0 = bottom row, like rt_render)."""
+    if len(xy):
+        frame[xy[:, 1], xy[:, 0]] = rgb
+    return frame
+
+
+def gather_rows(local_rows, max_rows, world_size, rank, dst=0):
+    """Gathers per-rank (rows_r, C) uint8 torch tensors of different lengths to
+    `dst`: padded to max_rows for the collective, the padding is the caller's to
+    drop (it knows every rank's row count).  Returns the padded list on dst."""
+    import torch
+    import torch.distributed as dist
+    padded = torch.zeros((max_rows,) + tuple(local_rows.shape[1:]), dtype=local_rows.dtype, device=local_rows.device)
+    padded[:len(local_rows)] = local_rows
+    if world_size == 1:
+        return [padded]
+    bufs = [torch.empty_like(padded) for _ in range(world_size)] if rank == dst else None
+    dist.gather(padded, gather_list=bufs, dst=dst)
+    return bufs
+
+
+def render_adaptive(ds, width, height, render_kw, aa_samples, aa_threshold, jitter, world_size, rank,
+                    tile=32, device="cuda"):
+    """Adaptive anti-aliasing of one frame over world_size ranks (this is rank
+    `rank`; ds is its DeviceScene).  Returns the finished (H, W, 3) uint8 frame
+    on rank 0 (numpy, row 0 = bottom row), None elsewhere."""
+    import torch
+    import torch.distributed as dist
+    from . import abi, device as dev, host
+
+    # pass 1: the base image, tiles interleaved over the ranks, complete everywhere
+    pad_px = max_shard_pixels(width, height, tile, tile, world_size)
+    packed = torch.zeros((pad_px, 3), dtype=torch.uint8, device=device)
+    p, _ = host.render_params(width, height, tile_w=tile, tile_h=tile, shard_index=rank,
+                              shard_count=world_size, out_is_device=True, **render_kw)
+    ds.render_device(p, packed.data_ptr())
+    if world_size > 1:
+        shards = [torch.empty_like(packed) for _ in range(world_size)]
+        dist.all_gather(shards, packed)
+    else:
+        shards = [packed]
+    frame_dev = torch.zeros((height, width, 3), dtype=torch.uint8, device=device)
+    for r, b in enumerate(shards):
+        dev.unpack_tiles(b.data_ptr(), 3, width, height, tile, tile, r, world_size, frame_dev.data_ptr(),
+                         torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    base = frame_dev.cpu().numpy()
+
+    # pass 2: this rank's share of the flagged pixels with n x n samples
+    xy = flagged_pixels(dev.edge_mask(base, aa_threshold))
+    mine = flagged_share(xy, rank, world_size)
+    pa, keep = host.render_params(width, height, aa_mode=abi.RT_AA_FULL, aa_samples=aa_samples, jitter=jitter,
+                                  **render_kw)
+    rgb, _ = ds.render_pixels(pa, mine)
+    most = (len(xy) + world_size - 1) // world_size
+    rows = gather_rows(torch.from_numpy(rgb).to(device), max(most, 1), world_size, rank)
+    if rank != 0:
+        return None
+    for r, b in enumerate(rows):
+        share = flagged_share(xy, r, world_size)
+        patch_pixels(base, share, b[:len(share)].cpu().numpy())
+    return base

@@ -290,3 +290,43 @@ def test_error_paths(built):
     with pytest.raises(device.DeviceError):
         device.DeviceScene(bad)
     ds.close()
+
+
+def test_adaptive_antialiasing_over_shards(built):
+    """The flagged pixels re-rendered share by share through rt_render_pixels,
+    on a base image assembled from tile shards, give the single-device adaptive
+    frame byte for byte (and the same number of rays)."""
+    from raytracer_amd import parallel
+    hs = host.HostScene(text=scenes.simple_scene())
+    ds = device.DeviceScene(hs.desc_ptr)
+    w, h, world = 120, 88, 3
+    jit = host.jitter_table(99, 3)
+    kw = dict(depth=2, traversal=abi.RT_TRAVERSE_FAST)
+    single, _, st1 = ds.render(host.render_params(w, h, aa_mode=abi.RT_AA_ADAPTIVE, aa_samples=3, aa_threshold=40,
+                                                  jitter=jit, **kw)[0])
+    base = np.zeros((h, w, 3), dtype=np.uint8)
+    rays = 0
+    for r in range(world):
+        st = ds.render_into(host.render_params(w, h, shard_index=r, shard_count=world, **kw)[0], base)
+        rays += st.rays_total
+    xy = parallel.flagged_pixels(device.edge_mask(base, 40))
+    assert len(xy) > 100
+    pa, keep = host.render_params(w, h, aa_mode=abi.RT_AA_FULL, aa_samples=3, jitter=jit, **kw)
+    out = base.copy()
+    for r in range(world):
+        share = parallel.flagged_share(xy, r, world)
+        rgb, st = ds.render_pixels(pa, share)
+        assert st.rays_primary == 9 * len(share)
+        rays += st.rays_total
+        parallel.patch_pixels(out, share, rgb)
+    assert np.array_equal(out, single)
+    assert rays == st1.rays_total
+    # the one-rank form of the distributed driver takes the same path
+    whole = parallel.render_adaptive(ds, w, h, kw, 3, 40, jit, 1, 0)
+    assert np.array_equal(whole, single)
+    # an empty list is fine
+    rgb, st = ds.render_pixels(pa, np.zeros((0, 2), dtype=np.int32))
+    assert len(rgb) == 0 and st.rays_total == 0
+    with pytest.raises(device.DeviceError):
+        ds.render_pixels(pa, np.array([[w, 0]], dtype=np.int32))
+    ds.close()

@@ -72,6 +72,29 @@ if rank == 0:
     print("GATHER_OK")
 else:
     assert bufs is None
+# adaptive anti-aliasing exchange: the base image complete on every rank (all-gather
+# of the packed shards), then the ranks' shares of the flagged pixels to rank 0
+shards = [torch.empty_like(torch.from_numpy(local)) for _ in range(world)]
+dist.all_gather(shards, torch.from_numpy(local))
+base = np.zeros_like(frame)
+for r, b in enumerate(shards):
+    parallel.unpack_host(b.numpy(), base, tw, th, r, world)
+assert np.array_equal(base, frame), "all-gathered base image differs"
+mask = np.where((xx + yy) % 5 == 0, 255, 0).astype(np.uint8)
+xy = parallel.flagged_pixels(mask)
+mine = parallel.flagged_share(xy, rank, world)
+rgb = np.stack([mine[:, 0] % 256, mine[:, 1] % 256, (mine[:, 0] + mine[:, 1]) % 256], axis=1).astype(np.uint8)
+most = (len(xy) + world - 1) // world
+rows = parallel.gather_rows(torch.from_numpy(rgb), most, world, rank)
+if rank == 0:
+    patched = base.copy()
+    for r, b in enumerate(rows):
+        share = parallel.flagged_share(xy, r, world)
+        parallel.patch_pixels(patched, share, b[:len(share)].numpy())
+    want = base.copy()
+    want[xy[:, 1], xy[:, 0]] = np.stack([xy[:, 0] % 256, xy[:, 1] % 256, (xy[:, 0] + xy[:, 1]) % 256], axis=1)
+    assert np.array_equal(patched, want), "patched frame differs"
+    print("ADAPTIVE_OK")
 t = torch.tensor([float(rank + 1)], dtype=torch.float64)
 dist.all_reduce(t, op=dist.ReduceOp.MAX)
 assert float(t[0]) == world
@@ -94,4 +117,4 @@ def test_gather_world_size_2_gloo(tmp_path):
                                       stderr=subprocess.STDOUT, text=True))
     outs = [p.communicate(timeout=240)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
-    assert "GATHER_OK" in outs[0]
+    assert "GATHER_OK" in outs[0] and "ADAPTIVE_OK" in outs[0]
