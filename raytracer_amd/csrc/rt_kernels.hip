@@ -45,6 +45,10 @@ using namespace rtd;
 namespace {
 
 constexpr int kBlock = 256;
+#ifndef RT_TRACE_BLOCK
+#define RT_TRACE_BLOCK 128
+#endif
+constexpr int kTraceBlock = RT_TRACE_BLOCK;   // threads per block of the traversal kernels
 
 struct Counters {           // device-resident, zeroed per level / per call
   unsigned int nsp;         // shade points appended at this level
@@ -197,7 +201,7 @@ __device__ __forceinline__ void flushCounters(const TraceCounters& c, Counters* 
 // slower on coherent rays: refilled lanes restart at the root and put the
 // wavefront's lanes out of phase between node and leaf work.)
 template <bool FAST, bool STATS>
-__global__ void __launch_bounds__(kBlock) RT_TRACE_ATTR
+__global__ void __launch_bounds__(kTraceBlock) RT_TRACE_ATTR
 k_trace(DevScene S, int n, RaySrc R, double* hitT, int* hitPrim, Counters* counters) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   TraceCounters tc{0, 0};
@@ -449,7 +453,7 @@ __device__ __forceinline__ V3 lightIntensityFrom(const DevScene& S, const RtLigh
 // acos, whose double-precision library code would nearly double it and halve
 // the wavefronts that hide the traversal's memory latency).
 template <bool FAST, bool STATS>
-__global__ void __launch_bounds__(kBlock) RT_TRACE_ATTR
+__global__ void __launch_bounds__(kTraceBlock) RT_TRACE_ATTR
 k_shadow(DevScene S, long long nMax, size_t spOff, Pool P) {
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const unsigned int nsp = P.counters->nsp;
@@ -1003,11 +1007,11 @@ struct RenderCtx {
 template <bool FAST, bool STATS>
 void launchTrace(RtScene* sc, int n, const RaySrc& R) {
   Pool& P = sc->pool;
-  k_trace<FAST, STATS><<<gridFor(n), kBlock, 0, sc->stream>>>(sc->dev, n, R, P.hitT, P.hitPrim, P.counters);
+  k_trace<FAST, STATS><<<(int)(((long long)n + kTraceBlock - 1) / kTraceBlock), kTraceBlock, 0, sc->stream>>>(sc->dev, n, R, P.hitT, P.hitPrim, P.counters);
 }
 template <bool FAST, bool STATS>
 void launchShadow(RtScene* sc, long long nMax, size_t spOff) {
-  k_shadow<FAST, STATS><<<gridFor(nMax), kBlock, 0, sc->stream>>>(sc->dev, nMax, spOff, sc->pool);
+  k_shadow<FAST, STATS><<<(int)((nMax + kTraceBlock - 1) / kTraceBlock), kTraceBlock, 0, sc->stream>>>(sc->dev, nMax, spOff, sc->pool);
 }
 
 bool timedBegin(RtScene* sc) {
