@@ -200,10 +200,29 @@ __device__ __forceinline__ void flushCounters(const TraceCounters& c, Counters* 
 // which a wavefront refills finished lanes from a run of rays was measured 1.6x
 // slower on coherent rays: refilled lanes restart at the root and put the
 // wavefront's lanes out of phase between node and leaf work.)
+// Workgroups are dealt to the 8 XCDs (each with its own L2) round-robin by
+// their index.  Consecutive rays look at neighbouring parts of the tree, so the
+// traversal kernels renumber their blocks in chunks: the kXcdChunk blocks that
+// XCD x receives in a row work on kXcdChunk consecutive pieces of the queue.
+// (Giving each XCD one contiguous eighth of the queue was 1.5x slower: sky and
+// terrain parts of a frame cost very different amounts.)
+#ifndef RT_XCD_CHUNK
+#define RT_XCD_CHUNK 32
+#endif
+__device__ __forceinline__ long long xcdBlock() {
+  constexpr unsigned int C = RT_XCD_CHUNK;
+  if (C <= 1) return blockIdx.x;
+  const unsigned int nb = gridDim.x, b = blockIdx.x, span = 8u * C;
+  const unsigned int full = nb / span * span;
+  if (b >= full) return b;
+  const unsigned int g = b / span, r = b % span;     // group of 8*C blocks, position in it
+  return (long long)g * span + (r & 7u) * C + (r >> 3);
+}
+
 template <bool FAST, bool STATS>
 __global__ void __launch_bounds__(kTraceBlock) RT_TRACE_ATTR
 k_trace(DevScene S, int n, RaySrc R, double* hitT, int* hitPrim, Counters* counters) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = (int)(xcdBlock() * blockDim.x + threadIdx.x);
   TraceCounters tc{0, 0};
   if (i < n) {
     V3 p, d;
@@ -455,7 +474,7 @@ __device__ __forceinline__ V3 lightIntensityFrom(const DevScene& S, const RtLigh
 template <bool FAST, bool STATS>
 __global__ void __launch_bounds__(kTraceBlock) RT_TRACE_ATTR
 k_shadow(DevScene S, long long nMax, size_t spOff, Pool P) {
-  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long idx = xcdBlock() * blockDim.x + threadIdx.x;
   const unsigned int nsp = P.counters->nsp;
   TraceCounters tc{0, 0};
   if (idx < nMax && idx < (long long)nsp * S.n_lights) {
