@@ -5,7 +5,9 @@ not available offline, so every scene is procedural.  Scalars are written with
 [0-9.-e] in numbers (src/parser/Tokenizer.cpp:229-237).
 
 Conventions that keep the reference's KD traversal equal to a true closest-hit
-query ("traversal modes"): trimeshes live under the identity
+query (its traversal takes only the far child when a ray origin lies exactly on
+a split plane, src/scene/scene.cpp:96-124, and tests mesh faces with the world
+ray against local boxes, src/scene/scene.cpp:13-36): trimeshes live under the identity
 transform with world-space vertices, and the camera eye uses coordinates that
 no object or face bounding box shares.
 """

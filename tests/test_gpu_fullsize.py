@@ -1,4 +1,4 @@
-"""GPU tests at the sizes BASELINE.json names (C1..C5).  Full frames are far
+"""GPU tests at the full sizes of the five benchmark configurations (C1..C5).  Full frames are far
 beyond what the CPU oracle renders in seconds, so each configuration is checked
 through (a) the oracle on a stratified pixel sample of the same frame, (b) the
 HIP reference-traversal path against the HIP fast path over the whole frame,
