@@ -84,6 +84,7 @@ struct Pool {
 // Shade-point material word: index into DevScene::devMats, or RT_SPM_INTERP when
 // the material was interpolated and lives in the per-point arrays.
 #define RT_PRIM_ANY (-2)                         // shadow query: some occluder in front of the light
+#define RT_SPM_PENDING 0xffffffffu               // k_surface left the point to k_surface_rest
 #define RT_SPM_INTERP 0x80000000u
 #define RT_SPM_LIT 0x40000000u                   // kd or ks non-zero: lights contribute
 #define RT_SPM_INDEX 0x3fffffffu
@@ -304,9 +305,15 @@ __device__ __forceinline__ unsigned int tileSlot(const TileScan& ts, int cls, in
 }
 
 // Misses take the background (RayTracer.cpp:213-224); hits become shade points.
+//
+// The common case -- a triangle whose material is one of the scene's materials
+// -- is finished here.  Hits on non-mesh objects and on meshes that interpolate
+// per-vertex materials only get their slot and are marked RT_SPM_PENDING for
+// k_surface_rest, and the cube-map background is left to k_background: the code
+// of those cases more than doubles the registers of this kernel, which waits on
+// gathers and needs its wavefronts.
 __global__ void __launch_bounds__(kBlock)
-k_surface(DevScene S, int n, int items, RaySrc R, size_t rayOff, size_t spOff, int level, int useCube,
-          int filterWidth, Pool P) {
+k_surface(DevScene S, int n, int items, RaySrc R, size_t rayOff, size_t spOff, int level, Pool P) {
   __shared__ TileScan ts;
   __shared__ unsigned int litCount;
   const int tileBase = blockIdx.x * kBlock * items;
@@ -327,12 +334,7 @@ k_surface(DevScene S, int n, int items, RaySrc R, size_t rayOff, size_t spOff, i
     const unsigned int s = tileSlot(ts, 0, k, isHit);
     if (i >= n) continue;
     if (!isHit) {
-      V3 bg(0.0, 0.0, 0.0);
-      if (useCube) {
-        V3 p, d;
-        if (rayOf(S, R, i, p, d) >= 0) bg = cubeColor(S, d, filterWidth);
-      }
-      storeV3(P.rayI, P.cap, rayOff + i, bg);
+      storeV3(P.rayI, P.cap, rayOff + i, V3(0.0, 0.0, 0.0));
       if (level == 0) P.primaryId[i] = 0;
       continue;
     }
@@ -341,46 +343,90 @@ k_surface(DevScene S, int n, int items, RaySrc R, size_t rayOff, size_t spOff, i
       continue;
     }
     const int prim = P.hitPrim[i];
-    V3 p, d;
-    const int type = rayOf(S, R, i, p, d);
-    const double t = P.hitT[i];
     const size_t g = spOff + s;
-    Surface sf;
-    bool lit;
-    int tableMat = -1;
+    P.spRayGlobal[g] = (int)(rayOff + i);
+    bool lean = false;
     if (prim & RT_PRIM_FACE) {
       const RtObject& o = S.objects[S.tris[prim & ~RT_PRIM_FACE].owner];
-      if (!(S.smooth && S.meshes[o.mesh].has_vertex_materials)) tableMat = o.material;
-    } else {
-      tableMat = S.objects[prim].material;
+      lean = !(S.smooth && S.meshes[o.mesh].has_vertex_materials);
+      if (lean) {
+        V3 p, d;
+        rayOf(S, R, i, p, d);
+        Surface sf;
+        surfaceAtFace(S, prim & ~RT_PRIM_FACE, p, d, sf, true);
+        const bool lit = (S.devMats[o.material].flags & (RT_MATF_KD | RT_MATF_KS)) != 0;   // material.cpp:50-53
+        P.spMat[g] = (int)((unsigned int)o.material | (lit ? RT_SPM_LIT : 0u));
+        if (level == 0) P.primaryId[i] = sf.objectID;
+        const V3 Q = p + (P.hitT[i] * d);                                // ray::at (ray.h:42-43)
+        storeV3(P.spQ, P.cap, s, Q);
+        storeV3(P.spN, P.cap, s, sf.N);
+        if (lit) myLit++;
+      }
     }
-    if (tableMat >= 0) {
-      surfaceAt(S, prim, p, d, type, sf, nullptr, false);
-      lit = (S.devMats[tableMat].flags & (RT_MATF_KD | RT_MATF_KS)) != 0;   // material.cpp:50-53
-      P.spMat[g] = (int)((unsigned int)tableMat | (lit ? RT_SPM_LIT : 0u));
-    } else {
-      MatD m;
-      surfaceAt(S, prim, p, d, type, sf, &m, false);
-      lit = !(iszero(m.kd) && iszero(m.ks));
-      P.spMat[g] = (int)(RT_SPM_INTERP | (lit ? RT_SPM_LIT : 0u));
-      storeV3(P.spKd, P.cap, s, m.kd);
-      storeV3(P.spKs, P.cap, s, m.ks);
-      P.spShin[s] = shininessOf(m);
-      storeV3(P.spShade, P.cap, g, m.ke + prod(m.ka, V3(S.ambient)));   // material.cpp:46
-      storeV3(P.spKr, P.cap, g, m.kr);
-      storeV3(P.spKt, P.cap, g, m.kt);
-      P.spIor[g] = intensityValue(m.index);                              // Material::index (material.h:217)
-    }
-    if (level == 0) P.primaryId[i] = sf.objectID;
-    const V3 Q = p + (t * d);                                            // ray::at (ray.h:42-43)
-    storeV3(P.spQ, P.cap, s, Q);
-    storeV3(P.spN, P.cap, s, sf.N);
-    P.spRayGlobal[g] = (int)(rayOff + i);
-    if (lit) myLit++;
+    if (!lean) P.spMat[g] = (int)RT_SPM_PENDING;
   }
   if (myLit) atomicAdd(&litCount, myLit);   // LDS atomic
   __syncthreads();
   if (threadIdx.x == 0 && litCount) atomicAdd(&P.counters->litsp, (unsigned long long)litCount);
+}
+
+// The shade points k_surface left pending: hits on spheres, boxes, squares,
+// cylinders and cones, and hits whose material is interpolated from per-vertex
+// materials.  One thread per shade point of the level.
+__global__ void __launch_bounds__(kBlock)
+k_surface_rest(DevScene S, int nMax, RaySrc R, size_t rayOff, size_t spOff, int level, Pool P) {
+  __shared__ unsigned int litCount;
+  if (threadIdx.x == 0) litCount = 0;
+  __syncthreads();
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned int nsp = P.counters->nsp;
+  if (s < nMax && (unsigned int)s < nsp && spOff + s < P.cap) {
+    const size_t g = spOff + s;
+    if ((unsigned int)P.spMat[g] == RT_SPM_PENDING) {
+      const int i = (int)((size_t)P.spRayGlobal[g] - rayOff);
+      const int prim = P.hitPrim[i];
+      V3 p, d;
+      const int type = rayOf(S, R, i, p, d);
+      const double t = P.hitT[i];
+      Surface sf;
+      bool lit;
+      const bool interp = (prim & RT_PRIM_FACE) != 0;   // pending faces are the interpolated ones
+      if (!interp) {
+        const int tableMat = S.objects[prim].material;
+        surfaceAt(S, prim, p, d, type, sf, nullptr, false);
+        lit = (S.devMats[tableMat].flags & (RT_MATF_KD | RT_MATF_KS)) != 0;   // material.cpp:50-53
+        P.spMat[g] = (int)((unsigned int)tableMat | (lit ? RT_SPM_LIT : 0u));
+      } else {
+        MatD m;
+        surfaceAt(S, prim, p, d, type, sf, &m, false);
+        lit = !(iszero(m.kd) && iszero(m.ks));
+        P.spMat[g] = (int)(RT_SPM_INTERP | (lit ? RT_SPM_LIT : 0u));
+        storeV3(P.spKd, P.cap, s, m.kd);
+        storeV3(P.spKs, P.cap, s, m.ks);
+        P.spShin[s] = shininessOf(m);
+        storeV3(P.spShade, P.cap, g, m.ke + prod(m.ka, V3(S.ambient)));   // material.cpp:46
+        storeV3(P.spKr, P.cap, g, m.kr);
+        storeV3(P.spKt, P.cap, g, m.kt);
+        P.spIor[g] = intensityValue(m.index);                              // Material::index (material.h:217)
+      }
+      if (level == 0) P.primaryId[i] = sf.objectID;
+      const V3 Q = p + (t * d);                                            // ray::at (ray.h:42-43)
+      storeV3(P.spQ, P.cap, s, Q);
+      storeV3(P.spN, P.cap, s, sf.N);
+      if (lit) atomicAdd(&litCount, 1u);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && litCount) atomicAdd(&P.counters->litsp, (unsigned long long)litCount);
+}
+
+// Cube-map background of the rays that hit nothing (RayTracer.cpp:213-224).
+__global__ void __launch_bounds__(kBlock)
+k_background(DevScene S, int n, RaySrc R, size_t rayOff, int filterWidth, Pool P) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || P.hitPrim[i] != RT_PRIM_NONE) return;
+  V3 p, d;
+  if (rayOf(S, R, i, p, d) >= 0) storeV3(P.rayI, P.cap, rayOff + i, cubeColor(S, d, filterWidth));
 }
 
 // Shadow query of one light from shade point Q (light.cpp:14-31,66-98,112-149):
@@ -868,6 +914,7 @@ struct RtScene {
   std::vector<void*> allocs;       // scene arrays
   int nLights = 0;
   int maxStackNeed = 0;
+  bool surfaceRest = false;        // some hits need k_surface_rest (non-mesh objects, interpolated materials)
   // workspace
   Pool pool;
   std::vector<void*> poolAllocs;
@@ -1079,9 +1126,11 @@ int renderBatch(RenderCtx& cx, long long first, int count, long long* slotsUsed)
     // entries per thread: enough tiles to fill the chip, few enough atomics
     const int items = std::min(kMaxItems, std::max(1, n / (kBlock * 2048)));
     const int tiles = (n + kBlock * items - 1) / (kBlock * items);
-    k_surface<<<tiles, kBlock, 0, sc->stream>>>(sc->dev, n, items, R, rayOff, spOff, level,
-                                                     rp.use_cubemap && sc->dev.cube_w > 0,
-                                                     rp.filter_width, P);
+    k_surface<<<tiles, kBlock, 0, sc->stream>>>(sc->dev, n, items, R, rayOff, spOff, level, P);
+    if (sc->surfaceRest)
+      k_surface_rest<<<gridFor(n), kBlock, 0, sc->stream>>>(sc->dev, n, R, rayOff, spOff, level, P);
+    if (rp.use_cubemap && sc->dev.cube_w > 0)
+      k_background<<<gridFor(n), kBlock, 0, sc->stream>>>(sc->dev, n, R, rayOff, rp.filter_width, P);
     const long long shadowThreads = (long long)n * sc->dev.n_lights;
     if (shadowThreads > 0) {
       const bool timed2 = timedBegin(sc);
@@ -1517,6 +1566,9 @@ int rt_scene_create(const RtSceneDesc* d, RtScene** out) {
   D.cull = d->backface_cull;
   D.smooth = d->smooth_shading;
   sc->nLights = d->n_lights;
+  sc->surfaceRest = D.interp_materials != 0;
+  for (int oi = 0; oi < d->n_objects; oi++)
+    if (d->objects[oi].kind != RT_OBJ_TRIMESH) sc->surfaceRest = true;
   *out = sc.release();
   return RT_OK;
 }

@@ -56,36 +56,46 @@ __device__ __forceinline__ MatD interpMaterial(const DevScene& S, int faceIdx, c
   return pm;
 }
 
+// isect of a winning triangle: barycentrics, interpolated or face normal in
+// world space, objectID (trimesh.cpp:173-204 after Geometry::intersect,
+// scene.cpp:13-36).  wantN false skips the normal.
+__device__ __forceinline__ void surfaceAtFace(const DevScene& S, int fi, const V3& p, const V3& d, Surface& sf,
+                                              bool wantN) {
+  const DevTri& T = S.tris[fi];
+  const RtObject& o = S.objects[T.owner];
+  const RtMesh& m = S.meshes[o.mesh];
+  const LocalRay lr = toLocal(o.inverse, p, d);
+  double rt;
+  V3 bary;
+  triTest<false>(T, lr.p, lr.d, false, rt, &bary);
+  sf.bary = bary;
+  sf.objectID = T.object_id;
+  if (wantN) {
+    V3 Nl;
+    if (S.smooth && m.has_vertex_normals) {
+      const double* fn = S.face_normals + 9 * (size_t)fi;
+      const V3 nA(fn), nB(fn + 3), nC(fn + 6);
+      Nl = (bary.x * nA) + (bary.y * nB) + (bary.z * nC);
+    } else {
+      Nl = V3(T.n);
+    }
+    Nl = normalized(Nl);
+    sf.N = normalized(mul33(o.normi, Nl));
+  }
+}
+
 // Full isect of the winning primitive: what Geometry::intersect +
 // <Primitive>::intersectLocal left in `i` for the closest candidate
-// (scene.cpp:13-36; trimesh.cpp:173-204).  `wantMat` false skips the material.
+// (scene.cpp:13-36; trimesh.cpp:173-204).  A null `mat` skips the material;
+// ktOnly skips the normal (shadow attenuation only needs the material).
 __device__ __forceinline__ void surfaceAt(const DevScene& S, int prim, const V3& p, const V3& d,
                                           int rayType, Surface& sf, MatD* mat, bool ktOnly) {
   if (prim & RT_PRIM_FACE) {
     const int fi = prim & ~RT_PRIM_FACE;
-    const DevTri& T = S.tris[fi];
-    const RtObject& o = S.objects[T.owner];
-    const RtMesh& m = S.meshes[o.mesh];
-    const LocalRay lr = toLocal(o.inverse, p, d);
-    double rt;
-    V3 bary;
-    triTest<false>(T, lr.p, lr.d, false, rt, &bary);
-    sf.bary = bary;
-    sf.objectID = T.object_id;
-    if (!ktOnly) {
-      V3 Nl;
-      if (S.smooth && m.has_vertex_normals) {
-        const double* fn = S.face_normals + 9 * (size_t)fi;
-        const V3 nA(fn), nB(fn + 3), nC(fn + 6);
-        Nl = (bary.x * nA) + (bary.y * nB) + (bary.z * nC);
-      } else {
-        Nl = V3(T.n);
-      }
-      Nl = normalized(Nl);
-      sf.N = normalized(mul33(o.normi, Nl));
-    }
+    surfaceAtFace(S, fi, p, d, sf, !ktOnly);
     if (mat) {
-      if (S.smooth && m.has_vertex_materials) *mat = interpMaterial(S, fi, bary);
+      const RtObject& o = S.objects[S.tris[fi].owner];
+      if (S.smooth && S.meshes[o.mesh].has_vertex_materials) *mat = interpMaterial(S, fi, sf.bary);
       else *mat = loadMat(S.materials[o.material]);
     }
   } else {
