@@ -573,6 +573,10 @@ __device__ __forceinline__ void shadePoint(const DevScene& S, const Pool& P, int
     V3 L;
     const V3 lightIntensity = lightIntensityFrom(S, S.lights[li], Q, sp == RT_PRIM_ANY ? RT_PRIM_NONE : sp, th,
                                                  sp == RT_PRIM_ANY, L);
+    // A light that contributes exactly zero (occluded by an opaque surface,
+    // outside a spot cone) adds +0 to every component whatever the Phong factors
+    // are (fmax keeps them finite, NaN included): skip their sqrt / pow.
+    if (iszero(lightIntensity)) continue;
     if (hasKd) I = I + prod(kd, lightIntensity) * fmax(dot(N, L), 0.0);
     if (hasKs) {
       const V3 view = normalized(V3(S.eye) - Q);             // material.cpp:66-67
