@@ -304,20 +304,13 @@ __device__ __forceinline__ unsigned int tileSlot(const TileScan& ts, int cls, in
   return ts.base[cls] + ts.cnt[cls][k][threadIdx.x >> 6] + (unsigned int)__popcll(m & ((1ull << lane) - 1ull));
 }
 
-// Misses take the background (RayTracer.cpp:213-224); hits become shade points.
-//
-// The common case -- a triangle whose material is one of the scene's materials
-// -- is finished here.  Hits on non-mesh objects and on meshes that interpolate
-// per-vertex materials only get their slot and are marked RT_SPM_PENDING for
-// k_surface_rest, and the cube-map background is left to k_background: the code
-// of those cases more than doubles the registers of this kernel, which waits on
-// gathers and needs its wavefronts.
+// Misses take the black background (RayTracer.cpp:213-224; a cube map is
+// added by k_background); hits get a shade-point slot (tile compaction) and are
+// handed to the surface kernels as RT_SPM_PENDING.
 __global__ void __launch_bounds__(kBlock)
-k_surface(DevScene S, int n, int items, RaySrc R, size_t rayOff, size_t spOff, int level, Pool P) {
+k_classify(int n, int items, size_t rayOff, size_t spOff, int level, Pool P) {
   __shared__ TileScan ts;
-  __shared__ unsigned int litCount;
   const int tileBase = blockIdx.x * kBlock * items;
-  if (threadIdx.x == 0) litCount = 0;
   unsigned int hitMask = 0;
   for (int k = 0; k < items; k++) {
     const int i = tileBase + k * kBlock + threadIdx.x;
@@ -327,7 +320,6 @@ k_surface(DevScene S, int n, int items, RaySrc R, size_t rayOff, size_t spOff, i
   }
   unsigned int tot0 = 0, tot1 = 0;
   tileReserve(ts, items, 1, &P.counters->nsp, tot0, tot1);
-  unsigned int myLit = 0;
   for (int k = 0; k < items; k++) {
     const int i = tileBase + k * kBlock + threadIdx.x;
     const bool isHit = (hitMask >> k) & 1u;
@@ -336,38 +328,41 @@ k_surface(DevScene S, int n, int items, RaySrc R, size_t rayOff, size_t spOff, i
     if (!isHit) {
       storeV3(P.rayI, P.cap, rayOff + i, V3(0.0, 0.0, 0.0));
       if (level == 0) P.primaryId[i] = 0;
-      continue;
-    }
-    if (spOff + s >= P.cap) {
+    } else if (spOff + s >= P.cap) {
       P.counters->overflow = 1;
-      continue;
+    } else {
+      P.spRayGlobal[spOff + s] = (int)(rayOff + i);
+      P.spMat[spOff + s] = (int)RT_SPM_PENDING;
     }
-    const int prim = P.hitPrim[i];
-    const size_t g = spOff + s;
-    P.spRayGlobal[g] = (int)(rayOff + i);
-    bool lean = false;
-    if (prim & RT_PRIM_FACE) {
-      const RtObject& o = S.objects[S.tris[prim & ~RT_PRIM_FACE].owner];
-      lean = !(S.smooth && S.meshes[o.mesh].has_vertex_materials);
-      if (lean) {
-        V3 p, d;
-        rayOf(S, R, i, p, d);
-        Surface sf;
-        surfaceAtFace(S, prim & ~RT_PRIM_FACE, p, d, sf, true);
-        const bool lit = (S.devMats[o.material].flags & (RT_MATF_KD | RT_MATF_KS)) != 0;   // material.cpp:50-53
-        P.spMat[g] = (int)((unsigned int)o.material | (lit ? RT_SPM_LIT : 0u));
-        if (level == 0) P.primaryId[i] = sf.objectID;
-        const V3 Q = p + (P.hitT[i] * d);                                // ray::at (ray.h:42-43)
-        storeV3(P.spQ, P.cap, s, Q);
-        storeV3(P.spN, P.cap, s, sf.N);
-        if (lit) myLit++;
-      }
-    }
-    if (!lean) P.spMat[g] = (int)RT_SPM_PENDING;
   }
-  if (myLit) atomicAdd(&litCount, myLit);   // LDS atomic
-  __syncthreads();
-  if (threadIdx.x == 0 && litCount) atomicAdd(&P.counters->litsp, (unsigned long long)litCount);
+}
+
+// One thread per shade point: the common case -- a triangle whose material is
+// one of the scene's materials -- is finished here.  Hits on non-mesh objects
+// and on meshes that interpolate per-vertex materials stay pending for
+// k_surface_rest: the code of those cases more than doubles the registers of
+// this kernel, which waits on gathers and needs its wavefronts.
+__global__ void __launch_bounds__(kBlock)
+k_surface(DevScene S, int nMax, RaySrc R, size_t rayOff, size_t spOff, int level, Pool P) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= nMax || (unsigned int)s >= P.counters->nsp || spOff + s >= P.cap) return;
+  const size_t g = spOff + s;
+  const int i = (int)((size_t)P.spRayGlobal[g] - rayOff);
+  const int prim = P.hitPrim[i];
+  if (!(prim & RT_PRIM_FACE)) return;
+  const int fi = prim & ~RT_PRIM_FACE;
+  const RtObject& o = S.objects[S.tris[fi].owner];
+  if (S.smooth && S.meshes[o.mesh].has_vertex_materials) return;
+  V3 p, d;
+  rayOf(S, R, i, p, d);
+  Surface sf;
+  surfaceAtFace(S, fi, p, d, sf, true);
+  const bool lit = (S.devMats[o.material].flags & (RT_MATF_KD | RT_MATF_KS)) != 0;   // material.cpp:50-53
+  P.spMat[g] = (int)((unsigned int)o.material | (lit ? RT_SPM_LIT : 0u));
+  if (level == 0) P.primaryId[i] = sf.objectID;
+  const V3 Q = p + (P.hitT[i] * d);                                    // ray::at (ray.h:42-43)
+  storeV3(P.spQ, P.cap, s, Q);
+  storeV3(P.spN, P.cap, s, sf.N);
 }
 
 // The shade points k_surface left pending: hits on spheres, boxes, squares,
@@ -375,9 +370,6 @@ k_surface(DevScene S, int n, int items, RaySrc R, size_t rayOff, size_t spOff, i
 // materials.  One thread per shade point of the level.
 __global__ void __launch_bounds__(kBlock)
 k_surface_rest(DevScene S, int nMax, RaySrc R, size_t rayOff, size_t spOff, int level, Pool P) {
-  __shared__ unsigned int litCount;
-  if (threadIdx.x == 0) litCount = 0;
-  __syncthreads();
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
   const unsigned int nsp = P.counters->nsp;
   if (s < nMax && (unsigned int)s < nsp && spOff + s < P.cap) {
@@ -413,11 +405,8 @@ k_surface_rest(DevScene S, int nMax, RaySrc R, size_t rayOff, size_t spOff, int 
       const V3 Q = p + (t * d);                                            // ray::at (ray.h:42-43)
       storeV3(P.spQ, P.cap, s, Q);
       storeV3(P.spN, P.cap, s, sf.N);
-      if (lit) atomicAdd(&litCount, 1u);
     }
   }
-  __syncthreads();
-  if (threadIdx.x == 0 && litCount) atomicAdd(&P.counters->litsp, (unsigned long long)litCount);
 }
 
 // Cube-map background of the rays that hit nothing (RayTracer.cpp:213-224).
@@ -606,11 +595,12 @@ __global__ void __launch_bounds__(kBlock)
 k_shade(DevScene S, int nMax, int items, int par, RaySrc R, size_t spOff, size_t rayOff, size_t nextRayOff,
         int depthLeft, Pool P) {
   __shared__ TileScan ts;
+  __shared__ unsigned int litCount;
   const unsigned int nsp = min((unsigned int)nMax, P.counters->nsp);
   const int tileBase = blockIdx.x * kBlock * items;
   if ((unsigned int)tileBase >= nsp) return;   // whole block, uniform
-  // pass 1: which children each shade point spawns
-  unsigned int reflMask = 0, refrMask = 0;
+  // pass 1: which children each shade point spawns (and how many points are lit)
+  unsigned int reflMask = 0, refrMask = 0, myLit = 0;
   for (int k = 0; k < items; k++) {
     const int s = tileBase + k * kBlock + threadIdx.x;
     bool wantRefl = false, wantRefr = false;
@@ -619,6 +609,7 @@ k_shade(DevScene S, int nMax, int items, int par, RaySrc R, size_t spOff, size_t
       const unsigned int mw = (unsigned int)P.spMat[g];
       const bool interp = (mw & RT_SPM_INTERP) != 0;
       const DevMat* dm = interp ? nullptr : &S.devMats[mw & RT_SPM_INDEX];
+      if (mw & RT_SPM_LIT) myLit++;
       if (depthLeft > 0) {
         wantRefl = interp ? !iszero(loadV3(P.spKr, P.cap, g)) : (dm->flags & RT_MATF_KR) != 0;
         if (interp ? !iszero(loadV3(P.spKt, P.cap, g)) : (dm->flags & RT_MATF_KT) != 0) {
@@ -637,11 +628,15 @@ k_shade(DevScene S, int nMax, int items, int par, RaySrc R, size_t spOff, size_t
     tileCount(ts, 0, k, wantRefl);
     tileCount(ts, 1, k, wantRefr);
   }
+  if (threadIdx.x == 0) litCount = 0;
   unsigned int nRefl = 0, nRefr = 0;
-  tileReserve(ts, items, 2, &P.counters->nnext, nRefl, nRefr);
+  tileReserve(ts, items, 2, &P.counters->nnext, nRefl, nRefr);   // has barriers before and after the scan
+  if (myLit) atomicAdd(&litCount, myLit);                         // LDS atomic
+  __syncthreads();
   if (threadIdx.x == 0) {
     if (nRefl) atomicAdd(&P.counters->refl, (unsigned long long)nRefl);
     if (nRefr) atomicAdd(&P.counters->refr, (unsigned long long)nRefr);
+    if (litCount) atomicAdd(&P.counters->litsp, (unsigned long long)litCount);
   }
   if (depthLeft <= 0) return;
   // pass 2: generate the rays into their slots
@@ -1130,7 +1125,8 @@ int renderBatch(RenderCtx& cx, long long first, int count, long long* slotsUsed)
     // entries per thread: enough tiles to fill the chip, few enough atomics
     const int items = std::min(kMaxItems, std::max(1, n / (kBlock * 2048)));
     const int tiles = (n + kBlock * items - 1) / (kBlock * items);
-    k_surface<<<tiles, kBlock, 0, sc->stream>>>(sc->dev, n, items, R, rayOff, spOff, level, P);
+    k_classify<<<tiles, kBlock, 0, sc->stream>>>(n, items, rayOff, spOff, level, P);
+    k_surface<<<gridFor(n), kBlock, 0, sc->stream>>>(sc->dev, n, R, rayOff, spOff, level, P);
     if (sc->surfaceRest)
       k_surface_rest<<<gridFor(n), kBlock, 0, sc->stream>>>(sc->dev, n, R, rayOff, spOff, level, P);
     if (rp.use_cubemap && sc->dev.cube_w > 0)
