@@ -220,7 +220,7 @@ __device__ __forceinline__ long long xcdBlock() {
   return (long long)g * span + (r & 7u) * C + (r >> 3);
 }
 
-template <bool FAST, bool STATS>
+template <bool FAST, bool STATS, bool TRI>
 __global__ void __launch_bounds__(kTraceBlock) RT_TRACE_ATTR
 k_trace(DevScene S, int n, RaySrc R, double* hitT, int* hitPrim, Counters* counters) {
   const int i = (int)(xcdBlock() * blockDim.x + threadIdx.x);
@@ -231,7 +231,7 @@ k_trace(DevScene S, int n, RaySrc R, double* hitT, int* hitPrim, Counters* count
     int prim = RT_PRIM_NONE;
     double t = 0.0;
     if (type >= 0) {
-      if (FAST) prim = traceBvh<false, STATS>(S, p, d, type, 1.0e308, -1.0, t, tc);
+      if (FAST) prim = traceBvh<false, STATS, TRI>(S, p, d, type, 1.0e308, -1.0, t, tc);
       else prim = traceKdReference<STATS>(S, p, d, type, t, tc);
     }
     hitT[i] = t;
@@ -422,14 +422,14 @@ k_background(DevScene S, int n, RaySrc R, size_t rayOff, int filterWidth, Pool P
 // the closest occluder `prim` at parameter `th`, or, when the scene is opaque
 // and the traversal may stop at any occluder in front of the light, just
 // whether there is one (`anyOccluder`).
-template <bool FAST, bool STATS>
+template <bool FAST, bool STATS, bool TRI>
 __device__ __forceinline__ void shadowQuery(const DevScene& S, const RtLight& l, const V3& Q, int& prim, double& th,
                                             bool& anyOccluder, TraceCounters& tc) {
   anyOccluder = false;
   if (l.type == RT_LIGHT_DIRECTIONAL) {
     const V3 sd = normalized(-V3(l.orientation));
     // any hit blacks a directional light out (light.cpp:21-24)
-    if (FAST) prim = traceBvh<true, STATS>(S, Q, sd, RT_RAY_SHADOW, 1.0e308, -1.0, th, tc);
+    if (FAST) prim = traceBvh<true, STATS, TRI>(S, Q, sd, RT_RAY_SHADOW, 1.0e308, -1.0, th, tc);
     else prim = traceKdReference<STATS>(S, Q, sd, RT_RAY_SHADOW, th, tc);
     return;
   }
@@ -442,10 +442,10 @@ __device__ __forceinline__ void shadowQuery(const DevScene& S, const RtLight& l,
   if (FAST && S.opaque) {
     // Every material has kt == 0, so the filter colour of ANY occluder in
     // front of the light is the closest occluder's: stop at the first one.
-    anyOccluder = traceBvh<true, STATS>(S, Q, sd, RT_RAY_SHADOW, limit, lightDistance, th, tc) != RT_PRIM_NONE;
+    anyOccluder = traceBvh<true, STATS, TRI>(S, Q, sd, RT_RAY_SHADOW, limit, lightDistance, th, tc) != RT_PRIM_NONE;
     prim = RT_PRIM_NONE;
   } else if (FAST) {
-    prim = traceBvh<false, STATS>(S, Q, sd, RT_RAY_SHADOW, limit, -1.0, th, tc);
+    prim = traceBvh<false, STATS, TRI>(S, Q, sd, RT_RAY_SHADOW, limit, -1.0, th, tc);
   } else {
     prim = traceKdReference<STATS>(S, Q, sd, RT_RAY_SHADOW, th, tc);
   }
@@ -506,7 +506,7 @@ __device__ __forceinline__ V3 lightIntensityFrom(const DevScene& S, const RtLigh
 // the kernel's register budget is the traversal's (the Phong terms need pow and
 // acos, whose double-precision library code would nearly double it and halve
 // the wavefronts that hide the traversal's memory latency).
-template <bool FAST, bool STATS>
+template <bool FAST, bool STATS, bool TRI>
 __global__ void __launch_bounds__(kTraceBlock) RT_TRACE_ATTR
 k_shadow(DevScene S, long long nMax, size_t spOff, Pool P) {
   const long long idx = xcdBlock() * blockDim.x + threadIdx.x;
@@ -520,7 +520,7 @@ k_shadow(DevScene S, long long nMax, size_t spOff, Pool P) {
       int prim;
       double th;
       bool anyOccluder;
-      shadowQuery<FAST, STATS>(S, S.lights[li], Q, prim, th, anyOccluder, tc);
+      shadowQuery<FAST, STATS, TRI>(S, S.lights[li], Q, prim, th, anyOccluder, tc);
       const size_t o = (size_t)li * P.cap + s;
       P.shPrim[o] = anyOccluder ? RT_PRIM_ANY : prim;
       if (P.shT) P.shT[o] = th;
@@ -913,6 +913,7 @@ struct RtScene {
   std::vector<void*> allocs;       // scene arrays
   int nLights = 0;
   int maxStackNeed = 0;
+  bool triOnly = true;             // nothing but triangles of identity-transform meshes: lean traversal kernels
   bool surfaceRest = false;        // some hits need k_surface_rest (non-mesh objects, interpolated materials)
   // workspace
   Pool pool;
@@ -1072,11 +1073,19 @@ struct RenderCtx {
 template <bool FAST, bool STATS>
 void launchTrace(RtScene* sc, int n, const RaySrc& R) {
   Pool& P = sc->pool;
-  k_trace<FAST, STATS><<<(int)(((long long)n + kTraceBlock - 1) / kTraceBlock), kTraceBlock, 0, sc->stream>>>(sc->dev, n, R, P.hitT, P.hitPrim, P.counters);
+  const int blocks = (int)(((long long)n + kTraceBlock - 1) / kTraceBlock);
+  if (FAST && sc->triOnly)
+    k_trace<FAST, STATS, true><<<blocks, kTraceBlock, 0, sc->stream>>>(sc->dev, n, R, P.hitT, P.hitPrim, P.counters);
+  else
+    k_trace<FAST, STATS, false><<<blocks, kTraceBlock, 0, sc->stream>>>(sc->dev, n, R, P.hitT, P.hitPrim, P.counters);
 }
 template <bool FAST, bool STATS>
 void launchShadow(RtScene* sc, long long nMax, size_t spOff) {
-  k_shadow<FAST, STATS><<<(int)((nMax + kTraceBlock - 1) / kTraceBlock), kTraceBlock, 0, sc->stream>>>(sc->dev, nMax, spOff, sc->pool);
+  const int blocks = (int)((nMax + kTraceBlock - 1) / kTraceBlock);
+  if (FAST && sc->triOnly)
+    k_shadow<FAST, STATS, true><<<blocks, kTraceBlock, 0, sc->stream>>>(sc->dev, nMax, spOff, sc->pool);
+  else
+    k_shadow<FAST, STATS, false><<<blocks, kTraceBlock, 0, sc->stream>>>(sc->dev, nMax, spOff, sc->pool);
 }
 
 bool timedBegin(RtScene* sc) {
@@ -1371,6 +1380,7 @@ int rt_scene_create(const RtSceneDesc* d, RtScene** out) {
       bool id = true;
       for (int k = 0; k < 16; k++) id = id && d->objects[i].inverse[k] == ((k % 5 == 0) ? 1.0 : 0.0);
       ownerIdentity[i] = id;
+      if (d->objects[i].kind != RT_OBJ_TRIMESH || !id) sc->triOnly = false;
     }
     std::vector<DevTri> tris((size_t)d->n_faces);
     std::vector<int> ids((size_t)d->n_faces * 3);

@@ -704,12 +704,17 @@ __device__ __forceinline__ void bvhSort4(float tn[4], int kid[4]) {
 // The primitives of leaf reference `ref` (< 0).  Closest hit: updates the best
 // hit.  Occlusion: returns true at the first hit that satisfies the reference's
 // test |(p + t d) - p|^2 < occDist2 (occDist2 < 0: any hit), with tHit set.
-template <bool ANYHIT, bool STATS>
+//
+// TRI: the scene holds nothing but triangles of identity-transform meshes (the
+// caller checked), so the code for the other primitive kinds and for object
+// space is left out -- it costs the traversal kernels a third of their
+// registers even when it never runs.
+template <bool ANYHIT, bool STATS, bool TRI>
 __device__ __forceinline__ bool bvhLeaf(const DevScene& S, const V3& p, const V3& d, const BvhRay& r, int ref,
                                         double occDist2, bool& haveOne, double& bestT, float& bestTf, int& bestPrim,
                                         double& tHit, TraceCounters& cnt) {
   const int x = ~ref;
-  if (x & RT_BVH_OBJECT_BIT) {
+  if (!TRI && (x & RT_BVH_OBJECT_BIT)) {
     const int oi = x & 0x3fffffff;
     double t;
     V3 N;
@@ -730,7 +735,7 @@ __device__ __forceinline__ bool bvhLeaf(const DevScene& S, const V3& p, const V3
       if (STATS) cnt.prims++;
       double rt, tw;
       bool hit;
-      if (T.axes & 16) {
+      if (TRI || (T.axes & 16)) {
         hit = triTest<true>(T, p, r.ldI, r.cullBack, rt, nullptr);
         tw = rt / r.lenI;
       } else {
@@ -761,12 +766,13 @@ __device__ __forceinline__ bool bvhLeaf(const DevScene& S, const V3& p, const V3
 // satisfies the reference's occlusion test |(p + t d) - p|^2 < occDist2
 // (light.cpp:77-80,123-126; occDist2 < 0: any hit counts, light.cpp:21), else
 // RT_PRIM_NONE.
-template <bool ANYHIT, bool STATS>
+template <bool ANYHIT, bool STATS, bool TRI = false>
 __device__ int traceBvh(const DevScene& S, const V3& p, const V3& d, int rayType, double tLimit,
                         double occDist2, double& tOut, TraceCounters& cnt) {
   tOut = 0.0;
   if (!S.bvh_valid) return RT_PRIM_NONE;
   if (anynan(d) || anynan(p)) {
+    if (TRI) return RT_PRIM_NONE;   // no triangle accepts a NaN ray, see bvhScanNaN
     double bt;
     const int bp = bvhScanNaN<STATS>(S, p, d, bt, cnt);
     if (!ANYHIT) { tOut = bt; return bp; }
@@ -840,7 +846,7 @@ __device__ int traceBvh(const DevScene& S, const V3& p, const V3& d, int rayType
       }
     } else {
       double tHit;
-      if (bvhLeaf<ANYHIT, STATS>(S, p, d, r, ref, occDist2, haveOne, bestT, bestTf, bestPrim, tHit, cnt)) {
+      if (bvhLeaf<ANYHIT, STATS, TRI>(S, p, d, r, ref, occDist2, haveOne, bestT, bestTf, bestPrim, tHit, cnt)) {
         tOut = tHit;
         return 0;
       }
