@@ -54,7 +54,7 @@ def main():
     tl = ["# %s: launch durations from the rocprofv3 kernel trace of `python3 bench.py` against bench.py's HIP events" % tag, "",
           "| kernel | launches (all) | avg ms (all, = rocprofv3 --stats) | timed launches | avg ms (timed launches) | bench.py HIP-event avg ms |",
           "|---|---|---|---|---|---|"]
-    for key, jk in (("k_trace<true, false>", "k_trace"), ("k_shadow<true, false>", "k_shadow")):
+    for key, jk in (("k_trace<true, false, true>", "k_trace"), ("k_shadow<true, false, true>", "k_shadow")):
         d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in rows if short(r["Kernel_Name"]) == key]
         n = int(round(bench["roofline"][jk]["launches_per_step"] * bench["steps"]))
         timed = d[-n:]
