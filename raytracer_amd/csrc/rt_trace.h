@@ -576,6 +576,8 @@ struct BvhRay {
   V3 ldI;                 // object-space direction of every identity-transform mesh
   double lenI;            // (Geometry::intersect, scene.cpp:17-20: ((p+d)-p) renormalised)
   float ivx, ivy, ivz;    // inv rounded to binary32
+  float pix, piy, piz;    // p * inv rounded to binary32
+  float epx, epy, epz;    // 2^-21 |p * inv|: the origin's share of a plane distance's rounding error
   bool negx, negy, negz;  // direction sign per axis (false on a degenerate axis)
   bool zx, zy, zz;        // |d| < 1e-30 on that axis: inside / outside test instead of a slab
   bool cullBack;
@@ -588,6 +590,8 @@ __device__ __forceinline__ void bvhRaySetup(const DevScene& S, const V3& p, cons
   r.zy = !(fabs(d.y) >= 1.0e-30);
   r.zz = !(fabs(d.z) >= 1.0e-30);
   r.ivx = (float)r.inv.x; r.ivy = (float)r.inv.y; r.ivz = (float)r.inv.z;
+  r.pix = (float)(p.x * r.inv.x); r.piy = (float)(p.y * r.inv.y); r.piz = (float)(p.z * r.inv.z);
+  r.epx = 0x1p-21f * fabsf(r.pix); r.epy = 0x1p-21f * fabsf(r.piy); r.epz = 0x1p-21f * fabsf(r.piz);
   r.negx = (d.x < 0.0) & !r.zx;
   r.negy = (d.y < 0.0) & !r.zy;
   r.negz = (d.z < 0.0) & !r.zz;
@@ -636,14 +640,18 @@ __device__ __forceinline__ void bvhNodeSlabs(const DevScene& S, const V3& p, con
   const int ex = (int)(int8_t)(w0.w & 255u), ey = (int)(int8_t)((w0.w >> 8) & 255u),
             ez = (int)(int8_t)((w0.w >> 16) & 255u);
   kid[0] = (int)w1.x; kid[1] = (int)w1.y; kid[2] = (int)w1.z; kid[3] = (int)w1.w;
-  // A = (origin - p) / d, B = 2^exp / d: plane q lies at distance A + q * B
-  const double ax = ((double)ox - p.x) * r.inv.x, ay = ((double)oy - p.y) * r.inv.y, az = ((double)oz - p.z) * r.inv.z;
+  // A = (origin - p) / d, B = 2^exp / d: plane q lies at distance A + q * B.
+  // All in binary32: A = origin * inv - p * inv (the second product once per ray);
+  // the roundings of both products, of their difference, of B and of the fused
+  // multiply-add stay below 2^-22 (|origin inv| + |p inv| + 255 |B|), half of
+  // what the planes are widened by.  (Far from the world origin the widening
+  // grows relative to the boxes: culling gets weaker, never wrong.)
   float bx = r.ivx * pow2f(ex), by = r.ivy * pow2f(ey), bz = r.ivz * pow2f(ez);
-  const float afx = (float)ax, afy = (float)ay, afz = (float)az;
-  // rounding of A, of B and of the fused multiply-add: < 2^-23 (|A| + 255 |B|)
-  const float errx = 0x1p-22f * fmaf(255.0f, fabsf(bx), fabsf(afx));
-  const float erry = 0x1p-22f * fmaf(255.0f, fabsf(by), fabsf(afy));
-  const float errz = 0x1p-22f * fmaf(255.0f, fabsf(bz), fabsf(afz));
+  const float oix = ox * r.ivx, oiy = oy * r.ivy, oiz = oz * r.ivz;
+  const float afx = oix - r.pix, afy = oiy - r.piy, afz = oiz - r.piz;
+  const float errx = fmaf(0x1p-21f, fmaf(255.0f, fabsf(bx), fabsf(oix)), r.epx);
+  const float erry = fmaf(0x1p-21f, fmaf(255.0f, fabsf(by), fabsf(oiy)), r.epy);
+  const float errz = fmaf(0x1p-21f, fmaf(255.0f, fabsf(bz), fabsf(oiz)), r.epz);
   float a0x = afx - errx, a1x = afx + errx;
   float a0y = afy - erry, a1y = afy + erry;
   float a0z = afz - errz, a1z = afz + errz;
