@@ -1504,6 +1504,23 @@ int rt_scene_create(const RtSceneDesc* d, RtScene** out) {
         else ordered[i] = tris[bvh.triOrder[i]];
       }
       DevTri* bt; HIP_TRY(upload(ordered.data(), ordered.size(), &bt)); keep(bt); D.bvhTris = bt;
+      if (sc->triOnly) {
+        std::vector<DevTriFast> fastTris(ordered.size());
+        for (size_t i = 0; i < ordered.size(); i++) {
+          const DevTri& T = ordered[i];
+          DevTriFast& F = fastTris[i];
+          const int ax = T.axes & 3, ay = (T.axes >> 2) & 3;
+          for (int a = 0; a < 3; a++) F.n[a] = T.n[a];
+          F.dconst = T.dconst;
+          F.a0 = T.v0[ax]; F.a1 = T.v0[ay];
+          F.b0 = T.v1[ax]; F.b1 = T.v1[ay];
+          F.c0 = T.v2[ax]; F.c1 = T.v2[ay];
+          F.abc = T.abc;
+          F.axes = ax | (ay << 2);
+          F.face = T.face;
+        }
+        DevTriFast* ft; HIP_TRY(upload(fastTris.data(), fastTris.size(), &ft)); keep(ft); D.bvhTrisFast = ft;
+      }
       static_assert(sizeof(rtbvh::Node4) == sizeof(DevBvhNode), "BVH node layouts differ");
       DevBvhNode* bn;
       HIP_TRY(upload(reinterpret_cast<const DevBvhNode*>(wide.nodes.data()), wide.nodes.size(), &bn));
