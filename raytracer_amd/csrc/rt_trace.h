@@ -852,7 +852,7 @@ __device__ int traceBvh(const DevScene& S, const V3& p, const V3& d, int rayType
   float topTn = 0.0f;
 #define RT_BVH_PUSH(R, T)                                                          \
   {                                                                                \
-    if (topRef != RT_BVH_EMPTY && sp < RT_BVH_STACK) {                             \
+    if (topRef != RT_BVH_EMPTY) {   /* depth checked at scene creation */          \
       stack[sp].ref = topRef;                                                      \
       if (!ANYHIT) stack[sp].tn = topTn;                                           \
       sp++;                                                                        \
