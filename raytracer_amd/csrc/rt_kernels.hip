@@ -1503,6 +1503,21 @@ int rt_scene_create(const RtSceneDesc* d, RtScene** out) {
         if (bvh.triOrder[i] & rtbvh::kObjectBit) std::memset(&ordered[i], 0, sizeof(DevTri));
         else ordered[i] = tris[bvh.triOrder[i]];
       }
+      // Unused child slots of a node point at a leaf of one null triangle (normal
+      // zero: every ray is parallel to it and rejected), so that the traversal
+      // needs no "is this slot used" test next to the slab test of its
+      // inverted box.
+      {
+        DevTri nullTri;
+        std::memset(&nullTri, 0, sizeof nullTri);
+        nullTri.axes = 0 | (1 << 2) | 16;
+        ordered.push_back(nullTri);
+        if (ordered.size() >= (1u << 27)) return fail(RT_ERR_UNSUPPORTED, "too many triangles for the BVH leaf encoding");
+        const int32_t nullLeaf = ~(int32_t)(((int32_t)(ordered.size() - 1) << 3) | 0);
+        for (rtbvh::Node4& n4 : wide.nodes)
+          for (int c = 0; c < 4; c++)
+            if (n4.child[c] == rtbvh::kEmptyChild) n4.child[c] = nullLeaf;
+      }
       DevTri* bt; HIP_TRY(upload(ordered.data(), ordered.size(), &bt)); keep(bt); D.bvhTris = bt;
       if (sc->triOnly) {
         std::vector<DevTriFast> fastTris(ordered.size());

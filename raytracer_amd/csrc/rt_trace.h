@@ -723,8 +723,10 @@ __device__ __forceinline__ void bvhNodeSlabs(const DevScene& S, const V3& p, con
     const float tnear0 = fmaxf(fmaxf(nx.x, ny.x), nz.x), tnear1 = fmaxf(fmaxf(nx.y, ny.y), nz.y);
     const float tfar0 = fminf(fminf(fminf(fx.x, fy.x), fz.x), bestTf);
     const float tfar1 = fminf(fminf(fminf(fx.y, fy.y), fz.y), bestTf);
-    const bool h0 = (kid[c] != RT_BVH_EMPTY) & (tnear0 <= tfar0) & (tfar0 >= 0.0f);
-    const bool h1 = (kid[c + 1] != RT_BVH_EMPTY) & (tnear1 <= tfar1) & (tfar1 >= 0.0f);
+    // (an unused slot has an inverted box; should rounding ever let one pass,
+    // it leads to a leaf of one null triangle)
+    const bool h0 = (tnear0 <= tfar0) & (tfar0 >= 0.0f);
+    const bool h1 = (tnear1 <= tfar1) & (tfar1 >= 0.0f);
     tn[c] = h0 ? tnear0 : kInf;
     tn[c + 1] = h1 ? tnear1 : kInf;
   }
