@@ -931,6 +931,7 @@ struct RtScene {
   size_t eventsUsed = 0;
   std::vector<unsigned char> eventKind;   // per pair: 0 k_trace, 1 k_lights
   hipEvent_t evStart = nullptr, evStop = nullptr;
+  Counters* countersHost = nullptr;   // pinned: the per-level read-back of the queue sizes
 
   ~RtScene() {
     if (stream) hipStreamSynchronize(stream);
@@ -941,6 +942,7 @@ struct RtScene {
     if (tileOffsets) hipFree(tileOffsets);
     if (jitterDev) hipFree(jitterDev);
     for (hipEvent_t e : events) hipEventDestroy(e);
+    if (countersHost) hipHostFree(countersHost);
     if (evStart) hipEventDestroy(evStart);
     if (evStop) hipEventDestroy(evStop);
     if (stream) hipStreamDestroy(stream);
@@ -1151,9 +1153,9 @@ int renderBatch(RenderCtx& cx, long long first, int count, long long* slotsUsed)
     k_lights<<<gridFor(n), kBlock, 0, sc->stream>>>(sc->dev, n, spOff, P);
     k_shade<<<tiles, kBlock, 0, sc->stream>>>(sc->dev, n, items, par, R, spOff, rayOff, rayOff + n,
                                               rp.depth - level, P);
-    Counters c;
-    HIP_TRY(hipMemcpyAsync(&c, P.counters, sizeof c, hipMemcpyDeviceToHost, sc->stream));
+    HIP_TRY(hipMemcpyAsync(sc->countersHost, P.counters, sizeof(Counters), hipMemcpyDeviceToHost, sc->stream));
     HIP_TRY(hipStreamSynchronize(sc->stream));
+    const Counters c = *sc->countersHost;
     if (c.overflow) return 1;
     levels.push_back({rayOff, spOff, n, (int)c.nsp});
     litTotal += c.litsp;
@@ -1351,6 +1353,7 @@ int rt_scene_create(const RtSceneDesc* d, RtScene** out) {
   std::memset(&sc->pool, 0, sizeof sc->pool);
   HIP_TRY(hipGetDevice(&sc->device));
   HIP_TRY(hipStreamCreateWithFlags(&sc->stream, hipStreamNonBlocking));
+  HIP_TRY(hipHostMalloc((void**)&sc->countersHost, sizeof(Counters), hipHostMallocDefault));
   HIP_TRY(hipEventCreate(&sc->evStart));
   HIP_TRY(hipEventCreate(&sc->evStop));
   DevScene& D = sc->dev;
