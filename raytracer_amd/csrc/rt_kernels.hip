@@ -59,6 +59,10 @@ struct Counters {           // device-resident, zeroed per level / per call
   unsigned long long shadowNodes, shadowPrims;   // of the shadow rays (k_lights)
 };
 
+// One counter block per recursion level, zeroed together when a batch starts
+// (levels past kCounterBlocks reuse them and zero their own).
+constexpr int kCounterBlocks = 64;
+
 struct Pool {
   size_t cap;                                    // slots
   // level-transient, double buffered by level parity
@@ -914,6 +918,7 @@ struct RtScene {
   int nLights = 0;
   int maxStackNeed = 0;
   bool triOnly = true;             // nothing but triangles of identity-transform meshes: lean traversal kernels
+  bool hasFaces = false;           // some mesh has triangles (else k_surface has nothing to do)
   bool surfaceRest = false;        // some hits need k_surface_rest (non-mesh objects, interpolated materials)
   // workspace
   Pool pool;
@@ -1025,7 +1030,7 @@ int ensurePool(RtScene* sc, size_t cap) {
   POOL_ALLOC(P.spKr, double, 3 * icap);
   POOL_ALLOC(P.spKt, double, 3 * icap);
   POOL_ALLOC(P.spIor, double, icap);
-  POOL_ALLOC(P.counters, Counters, 1);
+  POOL_ALLOC(P.counters, Counters, kCounterBlocks);
 #undef POOL_ALLOC
   P.cap = cap;
   sc->poolLights = nl;
@@ -1073,8 +1078,7 @@ struct RenderCtx {
 };
 
 template <bool FAST, bool STATS>
-void launchTrace(RtScene* sc, int n, const RaySrc& R) {
-  Pool& P = sc->pool;
+void launchTrace(RtScene* sc, const Pool& P, int n, const RaySrc& R) {
   const int blocks = (int)(((long long)n + kTraceBlock - 1) / kTraceBlock);
   if (FAST && sc->triOnly)
     k_trace<FAST, STATS, true><<<blocks, kTraceBlock, 0, sc->stream>>>(sc->dev, n, R, P.hitT, P.hitPrim, P.counters);
@@ -1082,12 +1086,12 @@ void launchTrace(RtScene* sc, int n, const RaySrc& R) {
     k_trace<FAST, STATS, false><<<blocks, kTraceBlock, 0, sc->stream>>>(sc->dev, n, R, P.hitT, P.hitPrim, P.counters);
 }
 template <bool FAST, bool STATS>
-void launchShadow(RtScene* sc, long long nMax, size_t spOff) {
+void launchShadow(RtScene* sc, const Pool& P, long long nMax, size_t spOff) {
   const int blocks = (int)((nMax + kTraceBlock - 1) / kTraceBlock);
   if (FAST && sc->triOnly)
-    k_shadow<FAST, STATS, true><<<blocks, kTraceBlock, 0, sc->stream>>>(sc->dev, nMax, spOff, sc->pool);
+    k_shadow<FAST, STATS, true><<<blocks, kTraceBlock, 0, sc->stream>>>(sc->dev, nMax, spOff, P);
   else
-    k_shadow<FAST, STATS, false><<<blocks, kTraceBlock, 0, sc->stream>>>(sc->dev, nMax, spOff, sc->pool);
+    k_shadow<FAST, STATS, false><<<blocks, kTraceBlock, 0, sc->stream>>>(sc->dev, nMax, spOff, P);
 }
 
 bool timedBegin(RtScene* sc) {
@@ -1112,32 +1116,35 @@ void timedEnd(RtScene* sc, int kind) {
 // RT_OK, an error, or +1 when the ray pool overflowed (caller splits the batch).
 int renderBatch(RenderCtx& cx, long long first, int count, long long* slotsUsed) {
   RtScene* sc = cx.sc;
-  Pool& P = sc->pool;
+  const Pool& pool = sc->pool;
   const RtRenderParams& rp = *cx.rp;
   const int ns = cx.fm.ns;
   const long long nSamples = (long long)count * ns;
-  if ((size_t)nSamples > P.cap) return 1;
+  if ((size_t)nSamples > pool.cap) return 1;
+  HIP_TRY(hipMemsetAsync(pool.counters, 0, sizeof(Counters) * kCounterBlocks, sc->stream));
   std::vector<LevelInfo> levels;
   int n = (int)nSamples, par = 0;
   size_t rayOff = 0, spOff = 0;
   unsigned long long litTotal = 0, nodes = 0, prims = 0, refl = 0, refr = 0, snodes = 0, sprims = 0;
   for (int level = 0; level <= rp.depth && n > 0; level++) {
-    HIP_TRY(hipMemsetAsync(P.counters, 0, sizeof(Counters), sc->stream));
+    Pool P = pool;   // this level's view of the pool: its own counter block
+    P.counters = pool.counters + (level % kCounterBlocks);
+    if (level >= kCounterBlocks) HIP_TRY(hipMemsetAsync(P.counters, 0, sizeof(Counters), sc->stream));
     RaySrc R;
     R.p = P.rayP[par]; R.d = P.rayD[par]; R.type = P.rayType[par]; R.stride = P.cap;
     R.primary = level == 0 ? 1 : 0;
     R.fm = cx.fm;
     R.firstSlot = first;
     const bool timed = timedBegin(sc);
-    if (cx.fast) { if (cx.wantStats) launchTrace<true, true>(sc, n, R); else launchTrace<true, false>(sc, n, R); }
-    else { if (cx.wantStats) launchTrace<false, true>(sc, n, R); else launchTrace<false, false>(sc, n, R); }
+    if (cx.fast) { if (cx.wantStats) launchTrace<true, true>(sc, P, n, R); else launchTrace<true, false>(sc, P, n, R); }
+    else { if (cx.wantStats) launchTrace<false, true>(sc, P, n, R); else launchTrace<false, false>(sc, P, n, R); }
     if (timed) timedEnd(sc, 0);
     cx.stats.trace_launches++;
     // entries per thread: enough tiles to fill the chip, few enough atomics
     const int items = std::min(kMaxItems, std::max(1, n / (kBlock * 2048)));
     const int tiles = (n + kBlock * items - 1) / (kBlock * items);
     k_classify<<<tiles, kBlock, 0, sc->stream>>>(n, items, rayOff, spOff, level, P);
-    k_surface<<<gridFor(n), kBlock, 0, sc->stream>>>(sc->dev, n, R, rayOff, spOff, level, P);
+    if (sc->hasFaces) k_surface<<<gridFor(n), kBlock, 0, sc->stream>>>(sc->dev, n, R, rayOff, spOff, level, P);
     if (sc->surfaceRest)
       k_surface_rest<<<gridFor(n), kBlock, 0, sc->stream>>>(sc->dev, n, R, rayOff, spOff, level, P);
     if (rp.use_cubemap && sc->dev.cube_w > 0)
@@ -1145,8 +1152,8 @@ int renderBatch(RenderCtx& cx, long long first, int count, long long* slotsUsed)
     const long long shadowThreads = (long long)n * sc->dev.n_lights;
     if (shadowThreads > 0) {
       const bool timed2 = timedBegin(sc);
-      if (cx.fast) { if (cx.wantStats) launchShadow<true, true>(sc, shadowThreads, spOff); else launchShadow<true, false>(sc, shadowThreads, spOff); }
-      else { if (cx.wantStats) launchShadow<false, true>(sc, shadowThreads, spOff); else launchShadow<false, false>(sc, shadowThreads, spOff); }
+      if (cx.fast) { if (cx.wantStats) launchShadow<true, true>(sc, P, shadowThreads, spOff); else launchShadow<true, false>(sc, P, shadowThreads, spOff); }
+      else { if (cx.wantStats) launchShadow<false, true>(sc, P, shadowThreads, spOff); else launchShadow<false, false>(sc, P, shadowThreads, spOff); }
       if (timed2) timedEnd(sc, 1);
       cx.stats.lights_launches++;
     }
@@ -1170,6 +1177,7 @@ int renderBatch(RenderCtx& cx, long long first, int count, long long* slotsUsed)
     n = (int)c.nnext;
     par ^= 1;
   }
+  const Pool& P = pool;
   for (int li = (int)levels.size() - 1; li >= 0; li--) {
     const LevelInfo& L = levels[li];
     if (L.nsp > 0) k_combine<<<gridFor(L.nsp), kBlock, 0, sc->stream>>>(sc->dev, L.spOff, L.nsp, P);
@@ -1611,6 +1619,7 @@ int rt_scene_create(const RtSceneDesc* d, RtScene** out) {
   D.cull = d->backface_cull;
   D.smooth = d->smooth_shading;
   sc->nLights = d->n_lights;
+  sc->hasFaces = d->n_faces > 0;
   sc->surfaceRest = D.interp_materials != 0;
   for (int oi = 0; oi < d->n_objects; oi++)
     if (d->objects[oi].kind != RT_OBJ_TRIMESH) sc->surfaceRest = true;
