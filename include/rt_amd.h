@@ -227,7 +227,10 @@ int rt_intersect_batch(RtScene* scene, int traversal, int n, const double* rays_
 /* Number of pixels / bytes of the packed tile buffer of one shard, and the
  * scatter of packed tiles back into a full frame on the device.  Packed layout:
  * the shard's tiles in increasing tile number, each tile row-major, clipped at
- * the frame border. */
+ * the frame border.  rt_unpack_tiles is ordered on hip_stream and returns
+ * without waiting for it: the caller synchronises that stream before it reads
+ * frame_dev from elsewhere.  The offset table of a (frame, tiling, shard) is
+ * built on its first use and kept for the life of the process. */
 long long rt_shard_pixels(int width, int height, int tile_w, int tile_h,
                           int shard_index, int shard_count);
 int rt_unpack_tiles(const unsigned char* packed_dev, int bytes_per_pixel,

@@ -33,6 +33,9 @@
 #include <memory>
 #include <string>
 #include <limits>
+#include <array>
+#include <map>
+#include <mutex>
 #include <vector>
 
 #include "../../include/rt_amd.h"
@@ -930,7 +933,6 @@ struct RtScene {
   bool growthMeasured = false;
   int growthDepth = -1;
   unsigned char* frameRgb = nullptr; int* frameHit = nullptr; size_t framePixels = 0;
-  long long* tileOffsets = nullptr; size_t tileOffsetsCap = 0;
   double* jitterDev = nullptr; size_t jitterCap = 0;
   std::vector<hipEvent_t> events;  // pairs around traversal kernels
   size_t eventsUsed = 0;
@@ -944,7 +946,6 @@ struct RtScene {
     freePool();
     if (frameRgb) hipFree(frameRgb);
     if (frameHit) hipFree(frameHit);
-    if (tileOffsets) hipFree(tileOffsets);
     if (jitterDev) hipFree(jitterDev);
     for (hipEvent_t e : events) hipEventDestroy(e);
     if (countersHost) hipHostFree(countersHost);
@@ -1061,6 +1062,31 @@ TileLayout tileLayout(int w, int h, int tw, int th, int shardIndex, int shardCou
     L.nTiles++;
   }
   return L;
+}
+
+// Device copies of packed-tile offset tables, one per (device, frame, tiling,
+// shard): rendering and unpacking a frame with the same geometry again reuses
+// the table instead of allocating and uploading it per call.  The tables live
+// until the process ends (a 4K frame's is 64 KiB).
+const long long* cachedTileOffsets(const TileLayout& TL, int w, int h, int tw, int th, int shardIndex,
+                                   int shardCount) {
+  static std::mutex mu;
+  static std::map<std::array<int, 7>, long long*> cache;
+  if (TL.offsets.empty()) return nullptr;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  const std::array<int, 7> key{dev, w, h, tw, th, shardIndex, shardCount};
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = cache.find(key);
+  if (it != cache.end()) return it->second;
+  long long* p = nullptr;
+  if (hipMalloc((void**)&p, TL.offsets.size() * sizeof(long long)) != hipSuccess) return nullptr;
+  if (hipMemcpy(p, TL.offsets.data(), TL.offsets.size() * sizeof(long long), hipMemcpyHostToDevice) != hipSuccess) {
+    hipFree(p);
+    return nullptr;
+  }
+  cache[key] = p;
+  return p;
 }
 
 struct LevelInfo { size_t rayOff, spOff; int n, nsp; };
@@ -1669,14 +1695,11 @@ int rt_render(RtScene* sc, const RtRenderParams* rp, unsigned char* rgb8_out, in
     const int rc = sizePool(sc, rp, (long long)TL.nTiles * rp->tile_w * rp->tile_h * nsFull);
     if (rc != RT_OK) return rc;
   }
-  if (TL.offsets.size() > sc->tileOffsetsCap) {
-    if (sc->tileOffsets) hipFree(sc->tileOffsets);
-    HIP_TRY(hipMalloc((void**)&sc->tileOffsets, TL.offsets.size() * sizeof(long long)));
-    sc->tileOffsetsCap = TL.offsets.size();
+  const long long* tileOffsets = nullptr;
+  if (rp->out_is_device && !TL.offsets.empty()) {
+    tileOffsets = cachedTileOffsets(TL, w, h, rp->tile_w, rp->tile_h, rp->shard_index, rp->shard_count);
+    if (!tileOffsets) return fail(RT_ERR_NOMEM, "cannot allocate the tile offset table");
   }
-  if (!TL.offsets.empty())
-    HIP_TRY(hipMemcpyAsync(sc->tileOffsets, TL.offsets.data(), TL.offsets.size() * sizeof(long long),
-                           hipMemcpyHostToDevice, sc->stream));
   {
     const int rc = uploadJitter(sc, rp, nsFull);
     if (rc != RT_OK) return rc;
@@ -1703,7 +1726,7 @@ int rt_render(RtScene* sc, const RtRenderParams* rp, unsigned char* rgb8_out, in
   cx.wantStats = rp->collect_stats != 0;
   cx.rgbDev = rp->out_is_device ? rgb8_out : sc->frameRgb;
   cx.hitDev = rp->out_is_device ? hit_id_out : sc->frameHit;
-  cx.tileOffDev = rp->out_is_device ? sc->tileOffsets : nullptr;
+  cx.tileOffDev = tileOffsets;
   FrameMap& fm = cx.fm;
   fm.width = w; fm.height = h;
   fm.tileW = rp->tile_w; fm.tileH = rp->tile_h; fm.tilesX = TL.tilesX;
@@ -1908,19 +1931,16 @@ int rt_unpack_tiles(const unsigned char* packed_dev, int bytes_per_pixel, int wi
   TileLayout TL = tileLayout(width, height, tile_w, tile_h, shard_index, shard_count);
   if (TL.nTiles == 0) return RT_OK;
   hipStream_t st = (hipStream_t)hip_stream;
-  long long* off = nullptr;
-  HIP_TRY(hipMalloc((void**)&off, TL.offsets.size() * sizeof(long long)));
-  HIP_TRY(hipMemcpyAsync(off, TL.offsets.data(), TL.offsets.size() * sizeof(long long), hipMemcpyHostToDevice, st));
+  const long long* off = cachedTileOffsets(TL, width, height, tile_w, tile_h, shard_index, shard_count);
+  if (!off) return fail(RT_ERR_NOMEM, "cannot allocate the tile offset table");
   FrameMap fm;
   std::memset(&fm, 0, sizeof fm);
   fm.width = width; fm.height = height; fm.tileW = tile_w; fm.tileH = tile_h; fm.tilesX = TL.tilesX;
   fm.shardIndex = shard_index; fm.shardCount = shard_count; fm.ns = 1;
   const long long slots = (long long)TL.nTiles * tile_w * tile_h;
   k_unpack<<<gridFor(slots), kBlock, 0, st>>>(packed_dev, bytes_per_pixel, fm, off, TL.nTiles, frame_dev);
-  hipError_t e = hipStreamSynchronize(st);
-  hipFree(off);
-  if (e != hipSuccess) return fail(RT_ERR_DEVICE, hipGetErrorString(e));
-  return RT_OK;
+  HIP_TRY(hipGetLastError());
+  return RT_OK;   // stream-ordered: the caller synchronises hip_stream
 }
 
 int rt_edge_mask(const unsigned char* rgb8, int width, int height, int cutoff, unsigned char* mask_out) {
