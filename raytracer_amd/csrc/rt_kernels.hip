@@ -71,19 +71,20 @@ struct Pool {
   // level-transient, double buffered by level parity
   double* rayP[2]; double* rayD[2]; int* rayType[2];
   double* hitT; int* hitPrim;
-  // shade points of the current level (indexed 0..nsp)
-  double* spQ; double* spN;
   // persistent for the whole batch (pool slot / pool shade-point index)
+  double* spQ; double* spN;
   double* rayI;
   double* spShade;
-  int* shPrim;                                   // [n_lights][cap] outcome of the shadow query per light
-  double* shT;                                   // [n_lights][cap] its hit parameter; NULL when the scene is opaque
+  // shadow queries of the current level ([n_lights][cap], indexed 0..nsp): written by
+  // k_shadow, read by k_lights
+  int* shPrim;                                   // outcome of the query per light
+  double* shT;                                   // its hit parameter; NULL when the scene is opaque
   int* spMat;                                    // RT_SPM_* word: material index, lit flag
   int* spChildRefl; int* spChildRefr; int* spRayGlobal;
   // only for shade points whose material is interpolated from vertex materials
   // (RT_SPM_INTERP); one-element stubs when the scene has none
-  double* spKd; double* spKs; double* spShin;    // by level index
-  double* spKr; double* spKt; double* spIor;     // by pool index
+  double* spKd; double* spKs; double* spShin;
+  double* spKr; double* spKt; double* spIor;
   int* primaryId;                                // objectID of the level-0 hit per sample
   Counters* counters;
 };
@@ -368,8 +369,8 @@ k_surface(DevScene S, int nMax, RaySrc R, size_t rayOff, size_t spOff, int level
   P.spMat[g] = (int)((unsigned int)o.material | (lit ? RT_SPM_LIT : 0u));
   if (level == 0) P.primaryId[i] = sf.objectID;
   const V3 Q = p + (P.hitT[i] * d);                                    // ray::at (ray.h:42-43)
-  storeV3(P.spQ, P.cap, s, Q);
-  storeV3(P.spN, P.cap, s, sf.N);
+  storeV3(P.spQ, P.cap, g, Q);
+  storeV3(P.spN, P.cap, g, sf.N);
 }
 
 // The shade points k_surface left pending: hits on spheres, boxes, squares,
@@ -400,9 +401,9 @@ k_surface_rest(DevScene S, int nMax, RaySrc R, size_t rayOff, size_t spOff, int 
         surfaceAt(S, prim, p, d, type, sf, &m, false);
         lit = !(iszero(m.kd) && iszero(m.ks));
         P.spMat[g] = (int)(RT_SPM_INTERP | (lit ? RT_SPM_LIT : 0u));
-        storeV3(P.spKd, P.cap, s, m.kd);
-        storeV3(P.spKs, P.cap, s, m.ks);
-        P.spShin[s] = shininessOf(m);
+        storeV3(P.spKd, P.cap, g, m.kd);
+        storeV3(P.spKs, P.cap, g, m.ks);
+        P.spShin[g] = shininessOf(m);
         storeV3(P.spShade, P.cap, g, m.ke + prod(m.ka, V3(S.ambient)));   // material.cpp:46
         storeV3(P.spKr, P.cap, g, m.kr);
         storeV3(P.spKt, P.cap, g, m.kt);
@@ -410,8 +411,8 @@ k_surface_rest(DevScene S, int nMax, RaySrc R, size_t rayOff, size_t spOff, int 
       }
       if (level == 0) P.primaryId[i] = sf.objectID;
       const V3 Q = p + (t * d);                                            // ray::at (ray.h:42-43)
-      storeV3(P.spQ, P.cap, s, Q);
-      storeV3(P.spN, P.cap, s, sf.N);
+      storeV3(P.spQ, P.cap, g, Q);
+      storeV3(P.spN, P.cap, g, sf.N);
     }
   }
 }
@@ -523,7 +524,7 @@ k_shadow(DevScene S, long long nMax, size_t spOff, Pool P) {
     const int li = (int)(idx / nsp);
     const int s = (int)(idx % nsp);
     if ((unsigned int)P.spMat[spOff + s] & RT_SPM_LIT) {
-      const V3 Q = loadV3(P.spQ, P.cap, s);
+      const V3 Q = loadV3(P.spQ, P.cap, spOff + s);
       int prim;
       double th;
       bool anyOccluder;
@@ -550,9 +551,9 @@ __device__ __forceinline__ void shadePoint(const DevScene& S, const Pool& P, int
   V3 kd, ks, I;
   double shin;
   if (interp) {
-    kd = loadV3(P.spKd, P.cap, s);
-    ks = loadV3(P.spKs, P.cap, s);
-    shin = P.spShin[s];
+    kd = loadV3(P.spKd, P.cap, g);
+    ks = loadV3(P.spKs, P.cap, g);
+    shin = P.spShin[g];
     I = loadV3(P.spShade, P.cap, g);
   } else {
     const DevMat& dm = S.devMats[mw & RT_SPM_INDEX];
@@ -593,7 +594,7 @@ k_lights(DevScene S, int nMax, size_t spOff, Pool P) {
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= nMax || (unsigned int)s >= P.counters->nsp) return;
   const size_t g = spOff + s;
-  shadePoint(S, P, s, g, (unsigned int)P.spMat[g], loadV3(P.spQ, P.cap, s), loadV3(P.spN, P.cap, s));
+  shadePoint(S, P, s, g, (unsigned int)P.spMat[g], loadV3(P.spQ, P.cap, g), loadV3(P.spN, P.cap, g));
 }
 
 // The secondary rays of RayTracer::traceRay (RayTracer.cpp:152-201).  Reflected rays of a tile are
@@ -622,7 +623,7 @@ k_shade(DevScene S, int nMax, int items, int par, RaySrc R, size_t spOff, size_t
         if (interp ? !iszero(loadV3(P.spKt, P.cap, g)) : (dm->flags & RT_MATF_KT) != 0) {
           V3 p, d;
           rayOf(S, R, (int)((size_t)P.spRayGlobal[g] - rayOff), p, d);
-          const double cosineAngle = acos(dot(loadV3(P.spN, P.cap, s), d)) * 180 / M_PI;
+          const double cosineAngle = acos(dot(loadV3(P.spN, P.cap, g), d)) * 180 / M_PI;
           wantRefr = cosineAngle < 360;  // RayTracer.cpp:173,195: false only for a NaN angle
         }
       } else {
@@ -659,8 +660,8 @@ k_shade(DevScene S, int nMax, int items, int par, RaySrc R, size_t spOff, size_t
     if (wantRefl || wantRefr) {
       V3 p, d;
       rayOf(S, R, (int)((size_t)P.spRayGlobal[g] - rayOff), p, d);
-      const V3 N = loadV3(P.spN, P.cap, s);
-      const V3 Q = loadV3(P.spQ, P.cap, s);
+      const V3 N = loadV3(P.spN, P.cap, g);
+      const V3 Q = loadV3(P.spQ, P.cap, g);
       const V3 minusD = -1 * d;
       const V3 cosVector = N * dot(minusD, N);
       const V3 sinVector = cosVector + d;
@@ -916,6 +917,11 @@ void invert4(const double* m, double* out) {
 struct RtScene {
   int device = 0;
   hipStream_t stream = nullptr;
+  // Shadow queries and shading of recursion level l run here beside the main
+  // stream's spawn / trace / surface kernels of level l+1 (see renderBatch).
+  hipStream_t side = nullptr;
+  hipEvent_t evSurface = nullptr, evSide = nullptr;   // main -> side, side -> main
+  int overlapMode = -1;            // RT_AMD_OVERLAP=0: everything on one stream
   DevScene dev;
   std::vector<void*> allocs;       // scene arrays
   int nLights = 0;
@@ -942,6 +948,7 @@ struct RtScene {
 
   ~RtScene() {
     if (stream) hipStreamSynchronize(stream);
+    if (side) hipStreamSynchronize(side);
     for (void* p : allocs) hipFree(p);
     freePool();
     if (frameRgb) hipFree(frameRgb);
@@ -951,6 +958,9 @@ struct RtScene {
     if (countersHost) hipHostFree(countersHost);
     if (evStart) hipEventDestroy(evStart);
     if (evStop) hipEventDestroy(evStop);
+    if (evSurface) hipEventDestroy(evSurface);
+    if (evSide) hipEventDestroy(evSide);
+    if (side) hipStreamDestroy(side);
     if (stream) hipStreamDestroy(stream);
   }
   void freePool() {
@@ -1112,15 +1122,15 @@ void launchTrace(RtScene* sc, const Pool& P, int n, const RaySrc& R) {
     k_trace<FAST, STATS, false><<<blocks, kTraceBlock, 0, sc->stream>>>(sc->dev, n, R, P.hitT, P.hitPrim, P.counters);
 }
 template <bool FAST, bool STATS>
-void launchShadow(RtScene* sc, const Pool& P, long long nMax, size_t spOff) {
+void launchShadow(RtScene* sc, hipStream_t st, const Pool& P, long long nMax, size_t spOff) {
   const int blocks = (int)((nMax + kTraceBlock - 1) / kTraceBlock);
   if (FAST && sc->triOnly)
-    k_shadow<FAST, STATS, true><<<blocks, kTraceBlock, 0, sc->stream>>>(sc->dev, nMax, spOff, P);
+    k_shadow<FAST, STATS, true><<<blocks, kTraceBlock, 0, st>>>(sc->dev, nMax, spOff, P);
   else
-    k_shadow<FAST, STATS, false><<<blocks, kTraceBlock, 0, sc->stream>>>(sc->dev, nMax, spOff, P);
+    k_shadow<FAST, STATS, false><<<blocks, kTraceBlock, 0, st>>>(sc->dev, nMax, spOff, P);
 }
 
-bool timedBegin(RtScene* sc) {
+bool timedBegin(RtScene* sc, hipStream_t st) {
   if (sc->eventsUsed + 2 > sc->events.size()) {
     for (int k = 0; k < 64; k++) {
       hipEvent_t e;
@@ -1128,11 +1138,11 @@ bool timedBegin(RtScene* sc) {
       sc->events.push_back(e);
     }
   }
-  hipEventRecord(sc->events[sc->eventsUsed], sc->stream);
+  hipEventRecord(sc->events[sc->eventsUsed], st);
   return true;
 }
-void timedEnd(RtScene* sc, int kind) {
-  hipEventRecord(sc->events[sc->eventsUsed + 1], sc->stream);
+void timedEnd(RtScene* sc, hipStream_t st, int kind) {
+  hipEventRecord(sc->events[sc->eventsUsed + 1], st);
   if (sc->eventKind.size() < sc->eventsUsed / 2 + 1) sc->eventKind.resize(sc->eventsUsed / 2 + 1);
   sc->eventKind[sc->eventsUsed / 2] = (unsigned char)kind;
   sc->eventsUsed += 2;
@@ -1148,6 +1158,18 @@ int renderBatch(RenderCtx& cx, long long first, int count, long long* slotsUsed)
   const long long nSamples = (long long)count * ns;
   if ((size_t)nSamples > pool.cap) return 1;
   HIP_TRY(hipMemsetAsync(pool.counters, 0, sizeof(Counters) * kCounterBlocks, sc->stream));
+  // A level's shadow queries and shading depend on its shade points only, the
+  // next level's rays on neither: they go to the side stream and run beside the
+  // main stream's k_shade of this level and k_trace / k_classify / k_surface of
+  // the next.  A thin level spends much of its time waiting for the dependent
+  // loads of its longest rays, and the shadow rays of the level above fill those
+  // gaps: 3 % of a 4K frame, 8 % of an eighth of it (one rank's share on 8 GPUs).
+  // RT_AMD_OVERLAP=0 keeps one stream (kernel durations without a neighbour);
+  // so do runs that collect traversal counters: the per-level read-back carries
+  // the shadow kernel's counters too.
+  const bool overlap = sc->dev.n_lights > 0 && !cx.wantStats && sc->overlapMode != 0;
+  hipStream_t lightStream = overlap ? sc->side : sc->stream;
+  bool sidePending = false;
   std::vector<LevelInfo> levels;
   int n = (int)nSamples, par = 0;
   size_t rayOff = 0, spOff = 0;
@@ -1155,16 +1177,20 @@ int renderBatch(RenderCtx& cx, long long first, int count, long long* slotsUsed)
   for (int level = 0; level <= rp.depth && n > 0; level++) {
     Pool P = pool;   // this level's view of the pool: its own counter block
     P.counters = pool.counters + (level % kCounterBlocks);
-    if (level >= kCounterBlocks) HIP_TRY(hipMemsetAsync(P.counters, 0, sizeof(Counters), sc->stream));
+    if (level >= kCounterBlocks) {
+      // the block is reused: the side stream may still read its old contents
+      if (sidePending) HIP_TRY(hipStreamWaitEvent(sc->stream, sc->evSide, 0));
+      HIP_TRY(hipMemsetAsync(P.counters, 0, sizeof(Counters), sc->stream));
+    }
     RaySrc R;
     R.p = P.rayP[par]; R.d = P.rayD[par]; R.type = P.rayType[par]; R.stride = P.cap;
     R.primary = level == 0 ? 1 : 0;
     R.fm = cx.fm;
     R.firstSlot = first;
-    const bool timed = timedBegin(sc);
+    const bool timed = timedBegin(sc, sc->stream);
     if (cx.fast) { if (cx.wantStats) launchTrace<true, true>(sc, P, n, R); else launchTrace<true, false>(sc, P, n, R); }
     else { if (cx.wantStats) launchTrace<false, true>(sc, P, n, R); else launchTrace<false, false>(sc, P, n, R); }
-    if (timed) timedEnd(sc, 0);
+    if (timed) timedEnd(sc, sc->stream, 0);
     cx.stats.trace_launches++;
     // entries per thread: enough tiles to fill the chip, few enough atomics
     const int items = std::min(kMaxItems, std::max(1, n / (kBlock * 2048)));
@@ -1175,21 +1201,32 @@ int renderBatch(RenderCtx& cx, long long first, int count, long long* slotsUsed)
       k_surface_rest<<<gridFor(n), kBlock, 0, sc->stream>>>(sc->dev, n, R, rayOff, spOff, level, P);
     if (rp.use_cubemap && sc->dev.cube_w > 0)
       k_background<<<gridFor(n), kBlock, 0, sc->stream>>>(sc->dev, n, R, rayOff, rp.filter_width, P);
+    if (overlap) {
+      HIP_TRY(hipEventRecord(sc->evSurface, sc->stream));
+      HIP_TRY(hipStreamWaitEvent(sc->side, sc->evSurface, 0));
+    }
     const long long shadowThreads = (long long)n * sc->dev.n_lights;
     if (shadowThreads > 0) {
-      const bool timed2 = timedBegin(sc);
-      if (cx.fast) { if (cx.wantStats) launchShadow<true, true>(sc, P, shadowThreads, spOff); else launchShadow<true, false>(sc, P, shadowThreads, spOff); }
-      else { if (cx.wantStats) launchShadow<false, true>(sc, P, shadowThreads, spOff); else launchShadow<false, false>(sc, P, shadowThreads, spOff); }
-      if (timed2) timedEnd(sc, 1);
+      const bool timed2 = timedBegin(sc, lightStream);
+      if (cx.fast) { if (cx.wantStats) launchShadow<true, true>(sc, lightStream, P, shadowThreads, spOff); else launchShadow<true, false>(sc, lightStream, P, shadowThreads, spOff); }
+      else { if (cx.wantStats) launchShadow<false, true>(sc, lightStream, P, shadowThreads, spOff); else launchShadow<false, false>(sc, lightStream, P, shadowThreads, spOff); }
+      if (timed2) timedEnd(sc, lightStream, 1);
       cx.stats.lights_launches++;
     }
-    k_lights<<<gridFor(n), kBlock, 0, sc->stream>>>(sc->dev, n, spOff, P);
+    k_lights<<<gridFor(n), kBlock, 0, lightStream>>>(sc->dev, n, spOff, P);
+    if (overlap) {
+      HIP_TRY(hipEventRecord(sc->evSide, sc->side));
+      sidePending = true;
+    }
     k_shade<<<tiles, kBlock, 0, sc->stream>>>(sc->dev, n, items, par, R, spOff, rayOff, rayOff + n,
                                               rp.depth - level, P);
     HIP_TRY(hipMemcpyAsync(sc->countersHost, P.counters, sizeof(Counters), hipMemcpyDeviceToHost, sc->stream));
     HIP_TRY(hipStreamSynchronize(sc->stream));
     const Counters c = *sc->countersHost;
-    if (c.overflow) return 1;
+    if (c.overflow) {
+      if (sidePending) HIP_TRY(hipStreamSynchronize(sc->side));
+      return 1;
+    }
     levels.push_back({rayOff, spOff, n, (int)c.nsp});
     litTotal += c.litsp;
     nodes += c.nodes;
@@ -1203,6 +1240,8 @@ int renderBatch(RenderCtx& cx, long long first, int count, long long* slotsUsed)
     n = (int)c.nnext;
     par ^= 1;
   }
+  // the colours of every level's shade points are needed from here on
+  if (sidePending) HIP_TRY(hipStreamWaitEvent(sc->stream, sc->evSide, 0));
   const Pool& P = pool;
   for (int li = (int)levels.size() - 1; li >= 0; li--) {
     const LevelInfo& L = levels[li];
@@ -1387,6 +1426,10 @@ int rt_scene_create(const RtSceneDesc* d, RtScene** out) {
   std::memset(&sc->pool, 0, sizeof sc->pool);
   HIP_TRY(hipGetDevice(&sc->device));
   HIP_TRY(hipStreamCreateWithFlags(&sc->stream, hipStreamNonBlocking));
+  HIP_TRY(hipStreamCreateWithFlags(&sc->side, hipStreamNonBlocking));
+  HIP_TRY(hipEventCreateWithFlags(&sc->evSurface, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&sc->evSide, hipEventDisableTiming));
+  if (const char* e = std::getenv("RT_AMD_OVERLAP")) sc->overlapMode = std::atoi(e) != 0 ? 1 : 0;
   HIP_TRY(hipHostMalloc((void**)&sc->countersHost, sizeof(Counters), hipHostMallocDefault));
   HIP_TRY(hipEventCreate(&sc->evStart));
   HIP_TRY(hipEventCreate(&sc->evStop));
