@@ -2,6 +2,13 @@
 // (src/fileio/bitmap.cpp:17-155): rows are stored bottom-up, the in-memory
 // buffer's row 0 is written first, pixels are RGB in memory and BGR on disk,
 // rows are padded to a multiple of four bytes, header = 14 + 40 bytes.
+// Two habits of the reference's writer are kept so that files compare equal:
+// bfSize counts the file header as sizeof(BMP_BITMAPFILEHEADER), which is 16 on
+// x86-64 (two bytes more than the file holds, bitmap.cpp:109), and the padding
+// bytes of a row are the leading bytes of the next row in memory, because the
+// scanline is copied with its padded length (bitmap.cpp:138-149).  The last
+// row's padding, which the reference reads from past the end of its buffer, is
+// zero here.
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -25,7 +32,7 @@ bool writeBMP(const std::string& path, int width, int height, const unsigned cha
   unsigned char hdr[54];
   std::memset(hdr, 0, sizeof hdr);
   put16(hdr + 0, 0x4d42);
-  put32(hdr + 2, 54 + (uint32_t)rowBytes * height);
+  put32(hdr + 2, 16 + 40 + (uint32_t)rowBytes * height);
   put32(hdr + 10, 54);
   put32(hdr + 14, 40);
   put32(hdr + 18, (uint32_t)width);
@@ -45,6 +52,7 @@ bool writeBMP(const std::string& path, int width, int height, const unsigned cha
       line[i * 3 + 1] = src[i * 3 + 1];
       line[i * 3 + 2] = src[i * 3 + 0];
     }
+    for (int k = 0; k < pad; k++) line[width * 3 + k] = (j + 1 < height) ? src[width * 3 + k] : 0;
     std::fwrite(line.data(), 1, rowBytes, f);
   }
   std::fclose(f);

@@ -215,6 +215,31 @@ def test_bmp_roundtrip_and_layout(built, tmp_path):
     assert int.from_bytes(raw[10:14], "little") == 54 and int.from_bytes(raw[28:30], "little") == 24
     assert raw[54:57] == bytes(img[0, 0, ::-1].tolist())          # buffer row 0 first, BGR
     assert np.array_equal(host.read_bmp(path), img)
+    # the reference writer's habits, from its source (src/fileio/bitmap.cpp:109,138-149):
+    # bfSize counts a 16-byte file header, and a row's padding is the start of
+    # the next row as it lies in memory (RGB, not swapped)
+    assert int.from_bytes(raw[2:6], "little") == 16 + 40 + 5 * 24
+    for j in range(4):
+        assert raw[54 + j * 24 + 21:54 + (j + 1) * 24] == bytes(img[j + 1, 0, :].tolist())
+    assert raw[54 + 4 * 24 + 21:] == b"\0\0\0"
+
+
+def test_bmp_header_fields_of_a_padless_frame(built, tmp_path):
+    """The 54 header bytes of a 512-wide frame, field by field as
+    src/fileio/bitmap.cpp:108-136 writes them on x86-64."""
+    img = np.zeros((4, 512, 3), np.uint8)
+    img[1, 2] = (10, 20, 30)
+    path = str(tmp_path / "h.bmp")
+    host.write_bmp(path, img)
+    raw = open(path, "rb").read()
+    le = lambda a, b: int.from_bytes(raw[a:b], "little")
+    n = 512 * 3 * 4
+    assert len(raw) == 54 + n
+    assert (le(0, 2), le(2, 6), le(6, 8), le(8, 10), le(10, 14)) == (0x4d42, 56 + n, 0, 0, 54)
+    assert (le(14, 18), le(18, 22), le(22, 26), le(26, 28), le(28, 30)) == (40, 512, 4, 1, 24)
+    assert (le(30, 34), le(34, 38), le(38, 42), le(42, 46), le(46, 50), le(50, 54)) == (0, 0, 2834, 2834, 0, 0)
+    off = 54 + (1 * 512 + 2) * 3
+    assert raw[off:off + 3] == bytes([30, 20, 10])
 
 
 def test_cubemap_install(built):
