@@ -1099,6 +1099,22 @@ const long long* cachedTileOffsets(const TileLayout& TL, int w, int h, int tw, i
   return p;
 }
 
+// Device allocation that lives as long as the call that made it, whichever
+// way the call returns.
+struct DevBuf {
+  void* p = nullptr;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  ~DevBuf() { if (p) hipFree(p); }
+  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes); }
+  hipError_t allocCopy(const void* host, size_t bytes) {
+    hipError_t e = alloc(bytes);
+    return e == hipSuccess ? hipMemcpy(p, host, bytes, hipMemcpyHostToDevice) : e;
+  }
+  template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
 struct LevelInfo { size_t rayOff, spOff; int n, nsp; };
 
 struct RenderCtx {
@@ -1788,22 +1804,22 @@ int rt_render(RtScene* sc, const RtRenderParams* rp, unsigned char* rgb8_out, in
   cx.stats.rays_primary = (unsigned long long)TL.pixels * fm.ns;
 
   std::vector<int> flagged;
-  int* listDev = nullptr;
+  DevBuf maskBuf, listBuf;
   if (rp->aa_mode == RT_AA_ADAPTIVE) {
     // GraphicalUI::doAntiAliasing (ui/GraphicalUI.cpp:377-435): edge mask on the
     // finished base image, then tracePixelAntiAlias on the flagged pixels only.
-    unsigned char* maskDev = nullptr;
-    HIP_TRY(hipMalloc((void**)&maskDev, (size_t)w * h));
+    HIP_TRY(maskBuf.alloc((size_t)w * h));
+    unsigned char* maskDev = maskBuf.as<unsigned char>();
     k_edge_mask<<<gridFor((long long)w * h), kBlock, 0, sc->stream>>>(sc->frameRgb, w, h, rp->aa_threshold, maskDev);
     std::vector<unsigned char> mask((size_t)w * h);
     HIP_TRY(hipMemcpyAsync(mask.data(), maskDev, mask.size(), hipMemcpyDeviceToHost, sc->stream));
     HIP_TRY(hipStreamSynchronize(sc->stream));
-    hipFree(maskDev);
     for (int y = 0; y < h; y++)
       for (int x = 0; x < w; x++)
         if (mask[(size_t)y * w + x] == 255) { flagged.push_back(x); flagged.push_back(y); }
     if (!flagged.empty()) {
-      HIP_TRY(hipMalloc((void**)&listDev, flagged.size() * sizeof(int)));
+      HIP_TRY(listBuf.alloc(flagged.size() * sizeof(int)));
+      int* listDev = listBuf.as<int>();
       HIP_TRY(hipMemcpyAsync(listDev, flagged.data(), flagged.size() * sizeof(int), hipMemcpyHostToDevice, sc->stream));
       fm.pixelList = listDev;
       fm.ns = nsFull;
@@ -1814,7 +1830,7 @@ int rt_render(RtScene* sc, const RtRenderParams* rp, unsigned char* rgb8_out, in
       rc = renderRange(cx, 0, nFlag);
       cx.hitDev = keepHit;
       cx.stats.rays_primary += (unsigned long long)nFlag * nsFull;
-      if (rc != RT_OK) { hipFree(listDev); return rc; }
+      if (rc != RT_OK) return rc;
     }
   }
   HIP_TRY(hipEventRecord(sc->evStop, sc->stream));
@@ -1846,7 +1862,6 @@ int rt_render(RtScene* sc, const RtRenderParams* rp, unsigned char* rgb8_out, in
   } else {
     HIP_TRY(hipStreamSynchronize(sc->stream));
   }
-  if (listDev) hipFree(listDev);
   // the next frame starts from this frame's overall growth, not from its worst batch
   if (cx.usedSamples > 0.0) sc->growth = 1.1 * cx.usedSlots / cx.usedSamples + 0.05;
 
@@ -1893,18 +1908,12 @@ int rt_render_pixels(RtScene* sc, const RtRenderParams* rp, int n_pixels, const 
   if (rc != RT_OK) return rc;
   rc = uploadJitter(sc, rp, ns);
   if (rc != RT_OK) return rc;
-  int* listDev = nullptr;
-  unsigned char* outDev = nullptr;
-  HIP_TRY(hipMalloc((void**)&listDev, (size_t)n_pixels * 2 * sizeof(int)));
-  if (hipMalloc((void**)&outDev, (size_t)n_pixels * 3) != hipSuccess) {
-    hipFree(listDev);
-    return fail(RT_ERR_NOMEM, "cannot allocate the pixel list output");
-  }
-  auto cleanup = [&] { hipFree(listDev); hipFree(outDev); };
-  if (hipMemcpyAsync(listDev, xy, (size_t)n_pixels * 2 * sizeof(int), hipMemcpyHostToDevice, sc->stream) != hipSuccess) {
-    cleanup();
-    return fail(RT_ERR_DEVICE, "pixel list upload failed");
-  }
+  DevBuf listBuf, outBuf;
+  HIP_TRY(listBuf.alloc((size_t)n_pixels * 2 * sizeof(int)));
+  if (outBuf.alloc((size_t)n_pixels * 3) != hipSuccess) return fail(RT_ERR_NOMEM, "cannot allocate the pixel list output");
+  int* listDev = listBuf.as<int>();
+  unsigned char* outDev = outBuf.as<unsigned char>();
+  HIP_TRY(hipMemcpyAsync(listDev, xy, (size_t)n_pixels * 2 * sizeof(int), hipMemcpyHostToDevice, sc->stream));
   cx.fast = rp->traversal == RT_TRAVERSE_FAST;
   cx.wantStats = rp->collect_stats != 0;
   cx.rgbDev = outDev;
@@ -1920,14 +1929,15 @@ int rt_render_pixels(RtScene* sc, const RtRenderParams* rp, int n_pixels, const 
   fm.aaN = (rp->aa_mode == RT_AA_NONE) ? 0 : rp->aa_samples;
   fm.jitter = (rp->aa_mode != RT_AA_NONE && rp->jitter) ? sc->jitterDev : nullptr;
   sc->eventsUsed = 0;
-  hipEventRecord(sc->evStart, sc->stream);
+  HIP_TRY(hipEventRecord(sc->evStart, sc->stream));
   rc = renderRange(cx, 0, n_pixels);
-  hipEventRecord(sc->evStop, sc->stream);
-  if (rc == RT_OK && hipMemcpyAsync(rgb8_out, outDev, (size_t)n_pixels * 3, hipMemcpyDeviceToHost, sc->stream) != hipSuccess)
-    rc = fail(RT_ERR_DEVICE, "pixel list download failed");
-  hipStreamSynchronize(sc->stream);
-  cleanup();
-  if (rc != RT_OK) return rc;
+  if (rc != RT_OK) {
+    hipStreamSynchronize(sc->stream);   // the buffers go away with this call
+    return rc;
+  }
+  HIP_TRY(hipEventRecord(sc->evStop, sc->stream));
+  HIP_TRY(hipMemcpyAsync(rgb8_out, outDev, (size_t)n_pixels * 3, hipMemcpyDeviceToHost, sc->stream));
+  HIP_TRY(hipStreamSynchronize(sc->stream));
   if (cx.usedSamples > 0.0) sc->growth = 1.1 * cx.usedSlots / cx.usedSamples + 0.05;
   cx.stats.rays_primary = (unsigned long long)n_pixels * ns;
   float ms = 0.f;
@@ -1947,20 +1957,17 @@ int rt_intersect_batch(RtScene* sc, int traversal, int n, const double* rays_pd,
   if (!sc || n < 0 || (n > 0 && (!rays_pd || !hits))) return fail(RT_ERR_INVALID, "bad argument");
   if (n == 0) return RT_OK;
   HIP_TRY(hipSetDevice(sc->device));
-  double* r = nullptr; int* ty = nullptr; RtHit* hd = nullptr;
-  HIP_TRY(upload(rays_pd, 6 * (size_t)n, &r));
-  if (ray_types) HIP_TRY(upload(ray_types, (size_t)n, &ty));
-  HIP_TRY(hipMalloc((void**)&hd, (size_t)n * sizeof(RtHit)));
+  DevBuf rays, types, hitBuf;
+  HIP_TRY(rays.allocCopy(rays_pd, 6 * (size_t)n * sizeof(double)));
+  if (ray_types) HIP_TRY(types.allocCopy(ray_types, (size_t)n * sizeof(int)));
+  HIP_TRY(hitBuf.alloc((size_t)n * sizeof(RtHit)));
   if (traversal == RT_TRAVERSE_FAST)
-    k_intersect<true><<<gridFor(n), kBlock, 0, sc->stream>>>(sc->dev, n, r, ty, hd);
+    k_intersect<true><<<gridFor(n), kBlock, 0, sc->stream>>>(sc->dev, n, rays.as<double>(), types.as<int>(), hitBuf.as<RtHit>());
   else
-    k_intersect<false><<<gridFor(n), kBlock, 0, sc->stream>>>(sc->dev, n, r, ty, hd);
-  hipError_t e = hipMemcpyAsync(hits, hd, (size_t)n * sizeof(RtHit), hipMemcpyDeviceToHost, sc->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(sc->stream);
-  hipFree(r);
-  if (ty) hipFree(ty);
-  hipFree(hd);
-  if (e != hipSuccess) return fail(RT_ERR_DEVICE, hipGetErrorString(e));
+    k_intersect<false><<<gridFor(n), kBlock, 0, sc->stream>>>(sc->dev, n, rays.as<double>(), types.as<int>(), hitBuf.as<RtHit>());
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(hits, hitBuf.p, (size_t)n * sizeof(RtHit), hipMemcpyDeviceToHost, sc->stream));
+  HIP_TRY(hipStreamSynchronize(sc->stream));
   return RT_OK;
 }
 
@@ -1989,14 +1996,12 @@ int rt_unpack_tiles(const unsigned char* packed_dev, int bytes_per_pixel, int wi
 int rt_edge_mask(const unsigned char* rgb8, int width, int height, int cutoff, unsigned char* mask_out) {
   if (!rgb8 || !mask_out || width <= 0 || height <= 0) return fail(RT_ERR_INVALID, "bad argument");
   const size_t px = (size_t)width * height;
-  unsigned char *src = nullptr, *dst = nullptr;
-  HIP_TRY(upload(rgb8, px * 3, &src));
-  HIP_TRY(hipMalloc((void**)&dst, px));
-  k_edge_mask<<<gridFor((long long)px), kBlock, 0, 0>>>(src, width, height, cutoff, dst);
-  hipError_t e = hipMemcpy(mask_out, dst, px, hipMemcpyDeviceToHost);
-  hipFree(src);
-  hipFree(dst);
-  if (e != hipSuccess) return fail(RT_ERR_DEVICE, hipGetErrorString(e));
+  DevBuf src, dst;
+  HIP_TRY(src.allocCopy(rgb8, px * 3));
+  HIP_TRY(dst.alloc(px));
+  k_edge_mask<<<gridFor((long long)px), kBlock, 0, 0>>>(src.as<unsigned char>(), width, height, cutoff, dst.as<unsigned char>());
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(mask_out, dst.p, px, hipMemcpyDeviceToHost));
   return RT_OK;
 }
 
