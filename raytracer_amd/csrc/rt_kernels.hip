@@ -359,14 +359,13 @@ k_surface(DevScene S, int nMax, RaySrc R, size_t rayOff, size_t spOff, int level
   const int prim = P.hitPrim[i];
   if (!(prim & RT_PRIM_FACE)) return;
   const int fi = prim & ~RT_PRIM_FACE;
-  const RtObject& o = S.objects[S.tris[fi].owner];
-  if (S.smooth && S.meshes[o.mesh].has_vertex_materials) return;
+  const int info = S.faceInfo[fi];
+  if (S.smooth && (info & RT_FI_VMATERIALS)) return;
   V3 p, d;
   rayOf(S, R, i, p, d);
   Surface sf;
-  surfaceAtFace(S, fi, p, d, sf, true);
-  const bool lit = (S.devMats[o.material].flags & (RT_MATF_KD | RT_MATF_KS)) != 0;   // material.cpp:50-53
-  P.spMat[g] = (int)((unsigned int)o.material | (lit ? RT_SPM_LIT : 0u));
+  surfaceNormalOfFace(S, fi, info, p, d, sf);
+  P.spMat[g] = (int)((unsigned int)(info & RT_FI_MATERIAL) | ((info & RT_FI_LIT) ? RT_SPM_LIT : 0u));   // material.cpp:50-53
   if (level == 0) P.primaryId[i] = sf.objectID;
   const V3 Q = p + (P.hitT[i] * d);                                    // ray::at (ray.h:42-43)
   storeV3(P.spQ, P.cap, g, Q);
@@ -1674,6 +1673,23 @@ int rt_scene_create(const RtSceneDesc* d, RtScene** out) {
   if (d->smooth_shading)
     for (int m = 0; m < d->n_meshes; m++)
       if (d->meshes[m].has_vertex_materials) D.interp_materials = 1;
+  D.faceInfo = nullptr;
+  if (d->n_faces > 0) {
+    if (d->n_materials > RT_FI_MATERIAL) return fail(RT_ERR_UNSUPPORTED, "too many materials");
+    std::vector<int> info((size_t)d->n_faces, 0);
+    for (int mi = 0; mi < d->n_meshes; mi++) {
+      const RtMesh& M = d->meshes[mi];
+      const RtMaterial& mat = d->materials[d->objects[M.object].material];
+      auto nz = [](const double* v) { return !(v[0] == 0.0 && v[1] == 0.0 && v[2] == 0.0); };
+      const int word = d->objects[M.object].material | ((nz(mat.kd) || nz(mat.ks)) ? RT_FI_LIT : 0) |
+                       (M.has_vertex_normals ? RT_FI_VNORMALS : 0) | (M.has_vertex_materials ? RT_FI_VMATERIALS : 0);
+      for (int f = 0; f < M.n_faces; f++) info[(size_t)M.first_face + f] = word;
+    }
+    int* p;
+    HIP_TRY(upload(info.data(), info.size(), &p));
+    keep(p);
+    D.faceInfo = p;
+  }
   if (d->vnormals) { double* p; HIP_TRY(upload(d->vnormals, 3 * (size_t)d->n_vertices, &p)); keep(p); D.vnormals = p; }
   if (d->vmaterials) { int* p; HIP_TRY(upload(d->vmaterials, (size_t)d->n_vertices, &p)); keep(p); D.vmaterials = p; }
   D.cube_w = D.cube_h = 0;

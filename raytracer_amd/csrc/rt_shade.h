@@ -84,6 +84,42 @@ __device__ __forceinline__ void surfaceAtFace(const DevScene& S, int fi, const V
   }
 }
 
+// surfaceAtFace's normal for a face whose RT_FI_* word is at hand.  A face of an
+// identity-transform mesh goes through the same arithmetic with the identity
+// written out (Geometry::intersect multiplies by the matrices whatever they
+// hold, scene.cpp:17-20, scene.h:168-172) instead of loading its owner.
+__device__ __forceinline__ void surfaceNormalOfFace(const DevScene& S, int fi, int info, const V3& p, const V3& d,
+                                                    Surface& sf) {
+  const DevTri& T = S.tris[fi];
+  const bool smoothN = S.smooth && (info & RT_FI_VNORMALS);
+  sf.objectID = T.object_id;
+  V3 Nl = V3(T.n);
+  if (T.axes & 16) {
+    const double I4[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    if (smoothN) {
+      const LocalRay lr = toLocal(I4, p, d);
+      double rt;
+      V3 bary;
+      triTest<false>(T, lr.p, lr.d, false, rt, &bary);
+      const double* fn = S.face_normals + 9 * (size_t)fi;
+      Nl = (bary.x * V3(fn)) + (bary.y * V3(fn + 3)) + (bary.z * V3(fn + 6));
+    }
+    sf.N = normalized(mul33(I3, normalized(Nl)));
+  } else {
+    const RtObject& o = S.objects[T.owner];
+    if (smoothN) {
+      const LocalRay lr = toLocal(o.inverse, p, d);
+      double rt;
+      V3 bary;
+      triTest<false>(T, lr.p, lr.d, false, rt, &bary);
+      const double* fn = S.face_normals + 9 * (size_t)fi;
+      Nl = (bary.x * V3(fn)) + (bary.y * V3(fn + 3)) + (bary.z * V3(fn + 6));
+    }
+    sf.N = normalized(mul33(o.normi, normalized(Nl)));
+  }
+}
+
 // Full isect of the winning primitive: what Geometry::intersect +
 // <Primitive>::intersectLocal left in `i` for the closest candidate
 // (scene.cpp:13-36; trimesh.cpp:173-204).  A null `mat` skips the material;

@@ -85,6 +85,14 @@ struct DevMat {
 #define RT_MATF_KR 4
 #define RT_MATF_KT 8
 
+// Per-face word: the owner's material index and lit flag, and whether the mesh
+// carries vertex normals / per-vertex materials, so that a hit on the face does
+// not have to walk face -> object -> mesh -> material.
+#define RT_FI_MATERIAL 0x0fffffff
+#define RT_FI_LIT 0x10000000      // the material's kd or ks is non-zero
+#define RT_FI_VNORMALS 0x20000000
+#define RT_FI_VMATERIALS 0x40000000
+
 struct DevScene {
   const DevMat* devMats;     // one per material
   int interp_materials;      // 1: some mesh interpolates per-vertex materials
@@ -98,6 +106,7 @@ struct DevScene {
   const RtLight* lights;
   const double* vnormals;    // 3 per global vertex
   const double* face_normals;  // 9 per face: the vertex normals of its corners (NULL: none / flat shading)
+  const int* faceInfo;         // RT_FI_* word per face: what a hit needs to know about its mesh and owner
   const int* vmaterials;     // material index per global vertex
   const unsigned char* cube[6];
   int cube_w, cube_h;
