@@ -784,7 +784,11 @@ __device__ __forceinline__ bool bvhLeaf(const DevScene& S, const V3& p, const V3
   } else {
     const int first = x >> 3, count = (x & 7) + 1;
     for (int k = 0; k < count; k++) {
+#ifdef RT_DIVERGENCE_STATS
+      if (STATS && (threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) cnt.prims++;
+#else
       if (STATS) cnt.prims++;
+#endif
       double rt, tw;
       bool hit;
       int face;
@@ -875,7 +879,11 @@ __device__ int traceBvh(const DevScene& S, const V3& p, const V3& d, int rayType
   const float kInf = __int_as_float(0x7f800000);
   for (;;) {
     if (ref >= 0) {
+#ifdef RT_DIVERGENCE_STATS   // diagnostics build: count wavefront iterations instead of lane visits
+      if (STATS && (threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) cnt.nodes++;
+#else
       if (STATS) cnt.nodes++;
+#endif
       float tn[4];
       int kid[4];
       bvhNodeSlabs(S, p, r, ref, bestTf, tn, kid);
