@@ -570,16 +570,22 @@ __device__ __forceinline__ void shadePoint(const DevScene& S, const Pool& P, int
     const V3 lightIntensity = lightIntensityFrom(S, S.lights[li], Q, sp == RT_PRIM_ANY ? RT_PRIM_NONE : sp, th,
                                                  sp == RT_PRIM_ANY, L);
     // A light that contributes exactly zero (occluded by an opaque surface,
-    // outside a spot cone) adds +0 to every component whatever the Phong factors
-    // are (fmax keeps them finite, NaN included): skip their sqrt / pow.
-    if (iszero(lightIntensity)) continue;
-    if (hasKd) I = I + prod(kd, lightIntensity) * fmax(dot(N, L), 0.0);
+    // outside a spot cone) adds +0 to every component when the Phong factors are
+    // finite: skip their sqrt / pow.  A NaN shade point (the hit of a NaN ray)
+    // makes the factors NaN, and the reference's 0 * NaN then poisons the colour.
+    if (iszero(lightIntensity) && !anynan(Q) && !anynan(N) && !anynan(L)) continue;
+    // std::max(x, 0.0) of material.cpp:61,72 is (x < 0.0) ? 0.0 : x -- it hands a NaN on
+    if (hasKd) {
+      const double c = dot(N, L);
+      I = I + prod(kd, lightIntensity) * ((c < 0.0) ? 0.0 : c);
+    }
     if (hasKs) {
       const V3 view = normalized(V3(S.eye) - Q);             // material.cpp:66-67
       const V3 cosVector = N * dot(L, N);
       const V3 sinVector = cosVector - L;
       const V3 refl = normalized(cosVector + sinVector);
-      I = I + prod(ks, lightIntensity) * pow(fmax(dot(refl, view), 0.0), shin);
+      const double c = dot(refl, view);
+      I = I + prod(ks, lightIntensity) * pow((c < 0.0) ? 0.0 : c, shin);
     }
   }
   storeV3(P.spShade, P.cap, g, I);

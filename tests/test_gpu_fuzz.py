@@ -1,0 +1,105 @@
+"""Seeded random scenes: every primitive kind under random affine transforms,
+random materials (specular, reflective, transmissive), one to three lights of
+random kinds, sometimes a small mesh under its own transform, random options.
+The HIP path must reproduce the CPU oracle on each of them:
+
+* RT_TRAVERSE_REFERENCE against the oracle on the same scene (KD-tree or linear
+  scan as the options say): byte-identical frame up to libm's pow / acos, equal
+  primary-hit ids, equal ray and shade-point counts;
+* RT_TRAVERSE_FAST against the oracle's linear scan (a true closest-hit query:
+  the reference's KD walk can lose hits whose ray starts on a split plane).
+"""
+import numpy as np
+import pytest
+
+from raytracer_amd import abi, device, host, scenes
+from oracle import loader
+from tests import common
+
+pytestmark = pytest.mark.gpu
+
+KINDS = ("sphere", "box", "cylinder", "cone", "square")
+
+
+def _rand_material(rng):
+    kd = rng.uniform(0.05, 0.9, size=3)
+    kw = dict(diffuse=tuple(kd), ambient=tuple(kd * rng.uniform(0.2, 1.0)))
+    if rng.rand() < 0.6:
+        kw.update(specular=tuple(rng.uniform(0.1, 0.9, size=3)), shininess=float(rng.uniform(2.0, 120.0)))
+    if rng.rand() < 0.4:
+        kw.update(reflective=tuple(rng.uniform(0.1, 0.8, size=3)))
+    if rng.rand() < 0.3:
+        kw.update(transmissive=tuple(rng.uniform(0.2, 0.9, size=3)), index=float(rng.uniform(1.05, 1.8)))
+    return scenes.material(**kw)
+
+
+def _rand_transform(rng, child, spread=3.0):
+    axis = rng.normal(size=3)
+    axis /= np.linalg.norm(axis)
+    child = scenes.scale(tuple(rng.uniform(0.5, 1.6, size=3)), child)
+    child = scenes.rotate(tuple(axis), float(rng.uniform(-3.0, 3.0)), child)
+    return scenes.translate((float(rng.uniform(-spread, spread)), float(rng.uniform(0.3, 2.6)),
+                             float(rng.uniform(-2.0, 3.0))), child)
+
+
+def random_scene(seed):
+    rng = np.random.RandomState(1000 + seed)
+    s = scenes.HEADER
+    s += scenes.camera((0.0371 + rng.uniform(-0.5, 0.5), 2.2137 + rng.uniform(-0.5, 0.5), -8.0213),
+                       (rng.uniform(-0.05, 0.05), -0.15, 1.0), aspect=1.3333333333, fov=float(rng.uniform(35.0, 55.0)))
+    s += scenes.ambient_light(tuple(rng.uniform(0.05, 0.3, size=3)))
+    for _ in range(rng.randint(1, 4)):
+        kind = rng.randint(3)
+        pos = (float(rng.uniform(-5, 5)), float(rng.uniform(4, 8)), float(rng.uniform(-6, 2)))
+        col = tuple(rng.uniform(0.4, 1.0, size=3))
+        if kind == 0:
+            s += scenes.point_light(pos, color=col)
+        elif kind == 1:
+            aim = np.array([rng.uniform(-1, 1), 0.5, rng.uniform(-1, 2)]) - np.array(pos)
+            s += scenes.spot_light(pos, tuple(aim / np.linalg.norm(aim)), color=col,
+                                   atten_angle=float(rng.uniform(15.0, 60.0)), fall_rate=float(rng.uniform(1.0, 12.0)))
+        else:
+            s += scenes.directional_light((float(rng.uniform(-0.5, 0.5)), -1.0, float(rng.uniform(-0.5, 0.5))),
+                                          color=tuple(np.array(col) * 0.5))
+    # a slightly tilted floor, so that no secondary ray starts exactly on a KD split plane
+    s += scenes.translate((0.0113, -0.0217, 0.0319), scenes.rotate((1.0, 0.013, 0.007), -1.5607963268,
+                          scenes.scale((16.0, 16.0, 1.0), scenes.prim("square", _rand_material(rng)))))
+    for _ in range(rng.randint(2, 8)):
+        kind = KINDS[rng.randint(len(KINDS))]
+        extra = ""
+        if kind == "cone":
+            extra = "height=%.4f; bottom_radius=%.4f; top_radius=%.4f; capped=%s;" % (
+                rng.uniform(0.8, 2.0), rng.uniform(0.4, 1.0), rng.uniform(0.0, 0.7), "true" if rng.rand() < 0.5 else "false")
+        s += _rand_transform(rng, scenes.prim(kind, _rand_material(rng), extra))
+    if rng.rand() < 0.7:
+        v, f = scenes.blob_mesh(1, seed=seed, radius=0.9, centre=(0.0, 0.0, 0.0))
+        mesh = scenes.trimesh(v, f, _rand_material(rng), gennormals=bool(rng.rand() < 0.6))
+        s += _rand_transform(rng, mesh, spread=2.0) if rng.rand() < 0.7 else scenes.translate((0.3117, 1.4113, 0.2119), mesh)
+    opts = dict(kd_tree=bool(rng.rand() < 0.7), backface_culling=bool(rng.rand() < 0.6),
+                smooth_shading=bool(rng.rand() < 0.7))
+    return s, opts
+
+
+def _counts(st):
+    return (st.rays_primary, st.rays_reflect, st.rays_refract, st.rays_shadow, st.shade_points)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_scene(built, seed):
+    text, opts = random_scene(seed)
+    w, h, depth = 112, 84, 3
+    hs = host.HostScene(text=text, **opts)
+    ds = device.DeviceScene(hs.desc_ptr)
+    p, _ = host.render_params(w, h, depth=depth, traversal=abi.RT_TRAVERSE_REFERENCE)
+    rgb, hits, st = ds.render(p)
+    rr, rh, rs = loader.render(hs.desc_ptr, p, threads=8)
+    common.assert_parity(rgb, hits, rr, rh, what="seed %d %s, reference traversal" % (seed, opts))
+    assert _counts(st) == _counts(rs)
+
+    pf, _ = host.render_params(w, h, depth=depth, traversal=abi.RT_TRAVERSE_FAST)
+    frgb, fhits, fst = ds.render(pf)
+    ds.close()
+    lin = host.HostScene(text=text, **dict(opts, kd_tree=False))
+    lr, lh, ls = loader.render(lin.desc_ptr, pf, threads=8)
+    common.assert_parity(frgb, fhits, lr, lh, what="seed %d %s, fast traversal vs linear scan" % (seed, opts))
+    assert _counts(fst) == _counts(ls)
