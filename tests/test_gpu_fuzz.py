@@ -1,6 +1,7 @@
 """Seeded random scenes: every primitive kind under random affine transforms,
 random materials (specular, reflective, transmissive), one to three lights of
-random kinds, sometimes a small mesh under its own transform, random options.
+random kinds, sometimes a small mesh under its own transform (now and then with
+per-vertex materials), random options.
 The HIP path must reproduce the CPU oracle on each of them:
 
 * RT_TRAVERSE_REFERENCE against the oracle on the same scene (KD-tree or linear
@@ -9,6 +10,8 @@ The HIP path must reproduce the CPU oracle on each of them:
 * RT_TRAVERSE_FAST against the oracle's linear scan (a true closest-hit query:
   the reference's KD walk can lose hits whose ray starts on a split plane).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -19,6 +22,8 @@ from tests import common
 pytestmark = pytest.mark.gpu
 
 KINDS = ("sphere", "box", "cylinder", "cone", "square")
+# RT_FUZZ_SEEDS=N widens both tests to N seeds each for a longer hunt
+N_SEEDS = int(os.environ.get("RT_FUZZ_SEEDS", "0"))
 
 
 def _rand_material(rng):
@@ -73,7 +78,8 @@ def random_scene(seed):
         s += _rand_transform(rng, scenes.prim(kind, _rand_material(rng), extra))
     if rng.rand() < 0.7:
         v, f = scenes.blob_mesh(1, seed=seed, radius=0.9, centre=(0.0, 0.0, 0.0))
-        mesh = scenes.trimesh(v, f, _rand_material(rng), gennormals=bool(rng.rand() < 0.6))
+        vm = [_rand_material(rng) for _ in range(len(v))] if rng.rand() < 0.3 else None   # per-vertex materials
+        mesh = scenes.trimesh(v, f, _rand_material(rng), gennormals=bool(rng.rand() < 0.6), vertex_materials=vm)
         s += _rand_transform(rng, mesh, spread=2.0) if rng.rand() < 0.7 else scenes.translate((0.3117, 1.4113, 0.2119), mesh)
     opts = dict(kd_tree=bool(rng.rand() < 0.7), backface_culling=bool(rng.rand() < 0.6),
                 smooth_shading=bool(rng.rand() < 0.7))
@@ -84,7 +90,7 @@ def _counts(st):
     return (st.rays_primary, st.rays_reflect, st.rays_refract, st.rays_shadow, st.shade_points)
 
 
-@pytest.mark.parametrize("seed", range(10))
+@pytest.mark.parametrize("seed", range(max(10, N_SEEDS)))
 def test_random_scene(built, seed):
     text, opts = random_scene(seed)
     w, h, depth = 112, 84, 3
@@ -100,6 +106,38 @@ def test_random_scene(built, seed):
     frgb, fhits, fst = ds.render(pf)
     ds.close()
     lin = host.HostScene(text=text, **dict(opts, kd_tree=False))
+    lr, lh, ls = loader.render(lin.desc_ptr, pf, threads=8)
+    common.assert_parity(frgb, fhits, lr, lh, what="seed %d %s, fast traversal vs linear scan" % (seed, opts))
+    assert _counts(fst) == _counts(ls)
+
+
+@pytest.mark.parametrize("seed", range(10, max(22, 10 + N_SEEDS)))
+def test_random_scene_cubemap_antialias_deep(built, seed):
+    """The same generator with a cube map behind the scene, 2x2 or 3x3 jittered
+    samples per pixel and recursion depth 4 or 5."""
+    text, opts = random_scene(seed)
+    rng = np.random.RandomState(seed)
+    n = int(rng.randint(2, 4))
+    depth = int(rng.randint(4, 6))
+    jit = host.jitter_table(777 + seed, n)
+    faces = scenes.cube_map_faces(32, seed=seed)
+    kw = dict(depth=depth, aa_mode=abi.RT_AA_FULL, aa_samples=n, jitter=jit, use_cubemap=True,
+              filter_width=int(rng.randint(1, 4)))
+    w, h = 72, 54
+    hs = host.HostScene(text=text, **opts)
+    hs.set_cubemap(faces)
+    ds = device.DeviceScene(hs.desc_ptr)
+    p, _ = host.render_params(w, h, traversal=abi.RT_TRAVERSE_REFERENCE, **kw)
+    rgb, hits, st = ds.render(p)
+    rr, rh, rs = loader.render(hs.desc_ptr, p, threads=8)
+    common.assert_parity(rgb, hits, rr, rh, what="seed %d %s, reference traversal" % (seed, opts))
+    assert _counts(st) == _counts(rs)
+
+    pf, _ = host.render_params(w, h, traversal=abi.RT_TRAVERSE_FAST, **kw)
+    frgb, fhits, fst = ds.render(pf)
+    ds.close()
+    lin = host.HostScene(text=text, **dict(opts, kd_tree=False))
+    lin.set_cubemap(faces)
     lr, lh, ls = loader.render(lin.desc_ptr, pf, threads=8)
     common.assert_parity(frgb, fhits, lr, lh, what="seed %d %s, fast traversal vs linear scan" % (seed, opts))
     assert _counts(fst) == _counts(ls)
