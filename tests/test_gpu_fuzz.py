@@ -141,3 +141,65 @@ def test_random_scene_cubemap_antialias_deep(built, seed):
     lr, lh, ls = loader.render(lin.desc_ptr, pf, threads=8)
     common.assert_parity(frgb, fhits, lr, lh, what="seed %d %s, fast traversal vs linear scan" % (seed, opts))
     assert _counts(fst) == _counts(ls)
+
+
+def random_mesh_scene(seed):
+    """Nothing but meshes with world-space vertices (identity transforms): the
+    scenes the lean triangle-only traversal kernels are compiled for."""
+    rng = np.random.RandomState(5000 + seed)
+    s = scenes.HEADER
+    s += scenes.camera((0.0371 + rng.uniform(-0.5, 0.5), 2.4137 + rng.uniform(-0.5, 0.5), -8.0213),
+                       (rng.uniform(-0.05, 0.05), -0.2, 1.0), aspect=1.3333333333, fov=float(rng.uniform(35.0, 55.0)))
+    s += scenes.ambient_light(tuple(rng.uniform(0.05, 0.3, size=3)))
+    s += scenes.point_light((float(rng.uniform(-4, 4)), float(rng.uniform(5, 8)), float(rng.uniform(-6, 0))))
+    if rng.rand() < 0.6:
+        pos = np.array([rng.uniform(-4, 4), rng.uniform(5, 8), rng.uniform(-5, 1)])
+        aim = np.array([rng.uniform(-1, 1), 0.5, rng.uniform(-1, 2)]) - pos
+        s += scenes.spot_light(tuple(pos), tuple(aim / np.linalg.norm(aim)), atten_angle=float(rng.uniform(20.0, 60.0)),
+                               fall_rate=float(rng.uniform(1.0, 10.0)))
+    if rng.rand() < 0.4:
+        s += scenes.directional_light((float(rng.uniform(-0.5, 0.5)), -1.0, float(rng.uniform(-0.5, 0.5))),
+                                      color=(0.4, 0.4, 0.4))
+    fv, ff = scenes.heightfield(int(rng.randint(6, 14)), extent=9.0, seed=seed, amplitude=float(rng.uniform(0.05, 0.4)))
+    s += scenes.trimesh(fv, ff, _rand_material(rng), gennormals=bool(rng.rand() < 0.5))
+    for k in range(rng.randint(1, 4)):
+        centre = (float(rng.uniform(-2.5, 2.5)), float(rng.uniform(1.2, 2.4)), float(rng.uniform(-1.5, 2.5)))
+        v, f = scenes.blob_mesh(int(rng.randint(0, 3)), seed=seed * 7 + k, radius=float(rng.uniform(0.5, 1.0)), centre=centre)
+        vm = [_rand_material(rng) for _ in range(len(v))] if rng.rand() < 0.25 else None
+        s += scenes.trimesh(v, f, _rand_material(rng), gennormals=bool(rng.rand() < 0.6), vertex_materials=vm)
+    opts = dict(kd_tree=bool(rng.rand() < 0.7), backface_culling=bool(rng.rand() < 0.5),
+                smooth_shading=bool(rng.rand() < 0.7), kd_max_depth=int(rng.randint(4, 18)), kd_leaf_size=int(rng.randint(1, 12)))
+    return s, opts
+
+
+@pytest.mark.parametrize("seed", range(max(10, N_SEEDS)))
+def test_random_mesh_only_scene_in_small_batches_and_shards(built, seed):
+    """Triangle-only scenes, rendered in several small batches (so that the level
+    pipeline of one batch runs into the next) and as three tile shards that are
+    put together on the host."""
+    text, opts = random_mesh_scene(seed)
+    rng = np.random.RandomState(seed)
+    w, h, depth = 96, 72, int(rng.randint(2, 5))
+    hs = host.HostScene(text=text, **opts)
+    ds = device.DeviceScene(hs.desc_ptr)
+    kw = dict(depth=depth, max_batch_samples=int(rng.choice([0, 256, 1024, 4096])))
+    p, _ = host.render_params(w, h, traversal=abi.RT_TRAVERSE_REFERENCE, **kw)
+    rgb, hits, st = ds.render(p)
+    rr, rh, rs = loader.render(hs.desc_ptr, p, threads=8)
+    common.assert_parity(rgb, hits, rr, rh, what="seed %d %s, reference traversal" % (seed, opts))
+    assert _counts(st) == _counts(rs)
+
+    lin = host.HostScene(text=text, **dict(opts, kd_tree=False))
+    pf, _ = host.render_params(w, h, traversal=abi.RT_TRAVERSE_FAST, **kw)
+    lr, lh, ls = loader.render(lin.desc_ptr, pf, threads=8)
+    frame = np.zeros((h, w, 3), np.uint8)
+    fhits = np.zeros((h, w), np.int32)
+    total = [0, 0, 0, 0, 0]
+    for shard in range(3):
+        ps, _ = host.render_params(w, h, traversal=abi.RT_TRAVERSE_FAST, tile_w=16, tile_h=8, shard_index=shard,
+                                   shard_count=3, **kw)
+        st_s = ds.render_into(ps, frame, fhits)
+        total = [a + b for a, b in zip(total, _counts(st_s))]
+    ds.close()
+    common.assert_parity(frame, fhits, lr, lh, what="seed %d %s, fast traversal in shards vs linear scan" % (seed, opts))
+    assert tuple(total) == _counts(ls)
