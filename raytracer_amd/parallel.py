@@ -120,6 +120,8 @@ def render_adaptive(ds, width, height, render_kw, aa_samples, aa_threshold, jitt
     packed = torch.zeros((pad_px, 3), dtype=torch.uint8, device=device)
     p, _ = host.render_params(width, height, tile_w=tile, tile_h=tile, shard_index=rank,
                               shard_count=world_size, out_is_device=True, **render_kw)
+    # the library renders on streams of its own: the fill above must be done first
+    torch.cuda.current_stream().synchronize()
     ds.render_device(p, packed.data_ptr())
     if world_size > 1:
         shards = [torch.empty_like(packed) for _ in range(world_size)]

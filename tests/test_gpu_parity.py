@@ -232,6 +232,7 @@ def test_sharded_tiles_assemble_to_single_device_frame(built):
             pd, _ = host.render_params(w, h, depth=2, tile_w=32, tile_h=16, shard_index=s,
                                        shard_count=shards, out_is_device=True)
             packed = torch.zeros((max(npx, 1), 3), dtype=torch.uint8, device="cuda")
+            torch.cuda.synchronize()   # the fill runs on torch's stream, the render on the library's
             ds.render_device(pd, packed.data_ptr())
             torch.cuda.synchronize()
             device.unpack_tiles(packed.data_ptr(), 3, w, h, 32, 16, s, shards, dev_frame.data_ptr(),
