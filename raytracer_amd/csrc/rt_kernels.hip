@@ -4,15 +4,20 @@
 // runs here as an iterative wavefront over recursion levels.  For one batch of
 // primary samples:
 //
-//   level L = 0 .. depth
-//     k_trace     closest hit of every ray of the level (Scene::intersect)
-//     k_surface   misses -> background colour; hits -> compacted shade points
-//                 (isect reconstruction: N, material, Q)
-//     k_lights    one thread per (light, shade point): shadow ray +
-//                 Light::{distance,shadow}Attenuation + the Phong terms
-//     k_shade     Material::shade's in-order sum over lights, then the
-//                 reflected / refracted rays of the next level, compacted per
-//                 wavefront into the next level's queue
+//   level L = 0 .. depth                              (main stream)
+//     k_trace     closest hit of every ray of the level (Scene::intersect);
+//                 level 0 generates its camera rays in place
+//     k_classify  misses -> black background; hits -> compacted shade-point slots
+//     k_surface   shade point of a triangle: Q, N, material word
+//                 (k_surface_rest: other primitives and interpolated materials;
+//                 k_background: cube map for the misses)
+//     k_shade     the reflected / refracted rays of the next level, compacted
+//                 into the next level's queue
+//                                                     (side stream, beside the
+//                                                      main stream's next level)
+//     k_shadow    one thread per (light, shade point): the shadow query
+//     k_lights    Material::shade: Light::{distance,shadow}Attenuation from the
+//                 query's outcome and the Phong terms, summed in light order
 //   level L = depth .. 0
 //     k_combine   I = shade + kr*I(reflected) + kt*I(refracted), i.e. the
 //                 additions of traceRay in the reference's order
@@ -53,7 +58,7 @@ constexpr int kBlock = 256;
 #endif
 constexpr int kTraceBlock = RT_TRACE_BLOCK;   // threads per block of the traversal kernels
 
-struct Counters {           // device-resident, zeroed per level / per call
+struct Counters {           // device-resident, one block per recursion level
   unsigned int nsp;         // shade points appended at this level
   unsigned int nnext;       // rays appended to the next level
   unsigned int overflow;    // pool exhausted
