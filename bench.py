@@ -133,18 +133,32 @@ def main():
     trav = abi.RT_TRAVERSE_FAST if args.traversal == "fast" else abi.RT_TRAVERSE_REFERENCE
     ds = device.DeviceScene(hs.desc_ptr)
     pad_px = parallel.max_shard_pixels(width, height, TILE, TILE, world)
-    packed = torch.zeros((pad_px, 3), dtype=torch.uint8, device="cuda")
+    # Two packed buffers, used in turn: the gather of frame k may still read its
+    # buffer on the backend's stream while the library renders frame k+1 on its
+    # own streams.  An event per buffer says when the gather that read it is done.
+    packed = [torch.zeros((pad_px, 3), dtype=torch.uint8, device="cuda") for _ in range(2)]
+    packed_free = [None, None]
+    gathered = [torch.empty_like(packed[0]) for _ in range(world)] if (rank == 0 and use_dist) else None
     frame = torch.zeros((height, width, 3), dtype=torch.uint8, device="cuda") if rank == 0 else None
     p, keep = host.render_params(width, height, traversal=trav, tile_w=TILE, tile_h=TILE,
                                  shard_index=rank, shard_count=world, out_is_device=True, **kw)
+    torch.cuda.synchronize()   # the fills above run on torch's stream, the renders on the library's
+    frames_done = [0]
 
     def step():
-        st = ds.render_device(p, packed.data_ptr())
-        bufs = parallel.gather_packed(packed, world, rank, force=use_dist)
+        k = frames_done[0] % 2
+        frames_done[0] += 1
+        if packed_free[k] is not None:
+            packed_free[k].synchronize()
+        st = ds.render_device(p, packed[k].data_ptr())
+        bufs = parallel.gather_packed(packed[k], world, rank, force=use_dist, out=gathered)
         if rank == 0:
             for r, b in enumerate(bufs):
                 device.unpack_tiles(b.data_ptr(), 3, width, height, TILE, TILE, r, world,
                                     frame.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        if packed_free[k] is None:
+            packed_free[k] = torch.cuda.Event()
+        packed_free[k].record()
         return st
 
     def fence():
@@ -186,7 +200,8 @@ def main():
         ps, keep2 = host.render_params(width, height, traversal=trav, tile_w=TILE, tile_h=TILE,
                                        shard_index=rank, shard_count=world, out_is_device=True,
                                        collect_stats=True, **kw)
-        sst = ds.render_device(ps, packed.data_ptr())
+        torch.cuda.synchronize()
+        sst = ds.render_device(ps, packed[0].data_ptr())
         svals = torch.tensor([float(sst.nodes_visited), float(sst.prims_tested), float(sst.rays_total),
                               float(sst.shadow_nodes_visited), float(sst.shadow_prims_tested),
                               float(sst.rays_shadow)], dtype=torch.float64, device="cuda")

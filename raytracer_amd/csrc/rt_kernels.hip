@@ -1451,8 +1451,17 @@ int rt_scene_create(const RtSceneDesc* d, RtScene** out) {
   std::memset(&sc->dev, 0, sizeof sc->dev);
   std::memset(&sc->pool, 0, sizeof sc->pool);
   HIP_TRY(hipGetDevice(&sc->device));
-  HIP_TRY(hipStreamCreateWithFlags(&sc->stream, hipStreamNonBlocking));
-  HIP_TRY(hipStreamCreateWithFlags(&sc->side, hipStreamNonBlocking));
+  // The main stream carries the chain of levels a frame cannot finish before;
+  // it gets the higher priority.  (The two priorities also keep the two streams
+  // on different hardware queues however many streams the process has made:
+  // streams of one priority share a small pool of queues, and two streams on
+  // one queue run their kernels one after the other.)
+  {
+    int least = 0, greatest = 0;
+    HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    HIP_TRY(hipStreamCreateWithPriority(&sc->stream, hipStreamNonBlocking, greatest));
+    HIP_TRY(hipStreamCreateWithPriority(&sc->side, hipStreamNonBlocking, std::min(least, greatest + 1)));
+  }
   HIP_TRY(hipEventCreateWithFlags(&sc->evSurface, hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&sc->evSide, hipEventDisableTiming));
   if (const char* e = std::getenv("RT_AMD_OVERLAP")) sc->overlapMode = std::atoi(e) != 0 ? 1 : 0;

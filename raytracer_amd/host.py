@@ -52,7 +52,7 @@ class HostScene:
 
     def __del__(self):
         h = getattr(self, "_h", None)
-        if h:
+        if h and lib is not None:   # module globals are gone when the interpreter shuts down
             lib().rth_scene_free(h)
             self._h = None
 

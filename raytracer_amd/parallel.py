@@ -51,16 +51,23 @@ def unpack_host(packed, frame, tile_w, tile_h, shard_index, shard_count):
     return frame
 
 
-def gather_packed(local_packed, world_size, rank, dst=0, force=False):
+def gather_packed(local_packed, world_size, rank, dst=0, force=False, out=None):
     """Gather equally sized (padded) packed buffers to `dst`.  local_packed is a
     torch tensor (pixels_padded, 3) uint8 on the backend's device.  Returns the
-    list of per-rank tensors on dst, None elsewhere.  A single rank skips the
-    collective unless `force` asks for it (to exercise the backend)."""
+    list of per-rank tensors on dst (`out`, a list of world_size tensors like
+    local_packed, when the caller keeps one), None elsewhere.  A single rank
+    skips the collective unless `force` asks for it (to exercise the backend).
+
+    The collective is ordered on the backend's stream: local_packed must not be
+    written again before it has run (record an event on the current stream after
+    this call and wait for it before the buffer's next use)."""
     import torch.distributed as dist
     if world_size == 1 and not force:
         return [local_packed]
     import torch
-    bufs = [torch.empty_like(local_packed) for _ in range(world_size)] if rank == dst else None
+    bufs = None
+    if rank == dst:
+        bufs = out if out is not None else [torch.empty_like(local_packed) for _ in range(world_size)]
     dist.gather(local_packed, gather_list=bufs, dst=dst)
     return bufs
 
