@@ -230,8 +230,13 @@ def main():
             try:
                 tj = json.load(open(tpath))
                 traffic = tj.get("k_trace_hbm_bytes_per_launch")
-                profiled = {"valu_busy_profiled": tj.get("k_trace_valu_busy"),
-                            "lanes_active_profiled": tj.get("k_trace_lanes_active"), "profile": tj.get("source")}
+                busy, lanes = tj.get("k_trace_valu_busy"), tj.get("k_trace_lanes_active")
+                profiled = {"valu_busy_profiled": busy, "lanes_active_profiled": lanes, "profile": tj.get("source"),
+                            # the VALU roof of the same kernel, from the committed counter pass: share of
+                            # cycles in which a SIMD issues a vector instruction, and of those the
+                            # share of lanes that do work
+                            "valu": {"bound": "valu issue", "issue_busy_frac": busy, "lanes_active_of_64": lanes,
+                                     "frac": round(busy * lanes / 64.0, 4) if busy and lanes else None}}
             except Exception:
                 traffic = None
         roof = {"bound": "hbm",
