@@ -331,3 +331,24 @@ def test_adaptive_antialiasing_over_shards(built):
     with pytest.raises(device.DeviceError):
         ds.render_pixels(pa, np.array([[w, 0]], dtype=np.int32))
     ds.close()
+
+
+def test_one_stream_and_two_streams_give_the_same_frame(built, monkeypatch):
+    """RT_AMD_OVERLAP=0 (read when the scene is created) keeps shadow queries and
+    shading on the main stream; the frame, the ids and the counts must not care."""
+    hs = host.HostScene(text=scenes.cornell_scene())
+    hs.set_cubemap(scenes.cube_map_faces(32, seed=2))
+    jit = host.jitter_table(99, 2)
+    kw = dict(width=120, height=68, depth=5, aa_mode=abi.RT_AA_FULL, aa_samples=2, jitter=jit, use_cubemap=True,
+              traversal=abi.RT_TRAVERSE_FAST, max_batch_samples=4096)
+    frames = []
+    for setting in ("0", "1"):
+        monkeypatch.setenv("RT_AMD_OVERLAP", setting)
+        ds = device.DeviceScene(hs.desc_ptr)
+        p, _ = host.render_params(**kw)
+        for _ in range(2):   # the second frame starts while nothing of the first is pending
+            rgb, hits, st = ds.render(p)
+        frames.append((rgb, hits, _ray_counts(st), st.shade_points))
+        ds.close()
+    assert np.array_equal(frames[0][0], frames[1][0]) and np.array_equal(frames[0][1], frames[1][1])
+    assert frames[0][2:] == frames[1][2:]
