@@ -809,6 +809,9 @@ __device__ __forceinline__ bool bvhLeaf(const DevScene& S, const V3& p, const V3
           tw = rt / lr.len;
         }
       }
+#if defined(RT_DIVERGENCE_STATS) && RT_DIVERGENCE_STATS == 2   // triangle iterations in which no lane hits
+      if (STATS && __ballot(hit) == 0 && (threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) cnt.nodes++;
+#endif
       if (!hit) continue;
       if (ANYHIT) {
         const V3 Qh = p + (tw * d);
@@ -880,7 +883,7 @@ __device__ int traceBvh(const DevScene& S, const V3& p, const V3& d, int rayType
   for (;;) {
     if (ref >= 0) {
 #ifdef RT_DIVERGENCE_STATS   // diagnostics build: count wavefront iterations instead of lane visits
-      if (STATS && (threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) cnt.nodes++;
+      if (STATS && RT_DIVERGENCE_STATS != 2 && (threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) cnt.nodes++;
 #else
       if (STATS) cnt.nodes++;
 #endif
