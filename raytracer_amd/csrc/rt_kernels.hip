@@ -102,6 +102,28 @@ struct Pool {
 #define RT_SPM_LIT 0x40000000u                   // kd or ks non-zero: lights contribute
 #define RT_SPM_INDEX 0x3fffffffu
 
+// Division of a 31-bit unsigned number by a divisor that is fixed for a launch
+// (tile size, tiles per row, samples per pixel): one multiply-high and a shift
+// instead of the few dozen instructions of a run-time division -- the sample ->
+// pixel mapping below runs once per primary ray in four kernels.
+// Granlund & Montgomery: with l = ceil(log2 d) and m = floor(2^(31+l) / d) + 1,
+// floor(n / d) = (m n) >> (31 + l) for every 0 <= n < 2^31.
+struct FastDiv {
+  unsigned int mul, shift, d;
+};
+inline FastDiv makeFastDiv(unsigned int d) {
+  FastDiv f{0u, 0u, d};
+  if (d <= 1u) return f;
+  unsigned int l = 0;
+  while ((1ull << l) < d) l++;
+  f.mul = (unsigned int)(((1ull << (31 + l)) / d) + 1ull);
+  f.shift = l - 1u;        // the multiply-high has already dropped 32 bits
+  return f;
+}
+__device__ __forceinline__ unsigned int fastDiv(unsigned int n, const FastDiv& f) {
+  return f.d <= 1u ? n : (__umulhi(n, f.mul) >> f.shift);
+}
+
 struct FrameMap {           // pixel slot -> pixel, for tile-ordered rendering
   int width, height;
   int tileW, tileH, tilesX;
@@ -111,30 +133,57 @@ struct FrameMap {           // pixel slot -> pixel, for tile-ordered rendering
   int ns;                   // samples per pixel
   int aaN;                  // n (ns = n*n) or 0
   const double* jitter;     // device copy, 2*ns values or NULL
+  FastDiv dPer, dTilesX, dBlocksPerRow, dNs, dAaN;   // by tileW*tileH, tilesX, tileW/8, ns, aaN (setDivisors)
 };
+
+// Fills the divisors from the sizes above (after every change of those).
+inline void setDivisors(FrameMap& fm) {
+  fm.dPer = makeFastDiv((unsigned int)(fm.tileW * fm.tileH));
+  fm.dTilesX = makeFastDiv((unsigned int)fm.tilesX);
+  fm.dBlocksPerRow = makeFastDiv((unsigned int)(fm.tileW >> 3));
+  fm.dNs = makeFastDiv((unsigned int)fm.ns);
+  fm.dAaN = makeFastDiv((unsigned int)std::max(1, fm.aaN));
+}
+
+// Where a batch (or a launch) starts in the slot order, split on the host so
+// that the device only divides 32-bit numbers: slot = tile * (tileW*tileH) + rem.
+struct SlotBase {
+  long long slot;           // first pixel slot
+  int tile;                 // slot / (tileW*tileH)
+  unsigned int rem;         // slot % (tileW*tileH)
+};
+inline SlotBase makeSlotBase(const FrameMap& fm, long long slot) {
+  const long long per = (long long)fm.tileW * fm.tileH;
+  return SlotBase{slot, (int)(slot / per), (unsigned int)(slot % per)};
+}
 
 // Pixel slot -> (x, y).  Slots enumerate this shard's tiles in increasing tile
 // number; inside a tile, 8x8 blocks row-major, pixels row-major in the block,
 // so one wavefront works on one 8x8 block.  Slots outside the frame are inactive.
-__device__ __forceinline__ bool slotToPixel(const FrameMap& fm, long long slot, int& x, int& y,
+__device__ __forceinline__ bool slotToPixel(const FrameMap& fm, const SlotBase& base, unsigned int rel, int& x, int& y,
                                             int& tileK, int& lx, int& ly) {
   if (fm.pixelList) {
+    const long long slot = base.slot + rel;
     x = fm.pixelList[2 * slot];
     y = fm.pixelList[2 * slot + 1];
     tileK = 0; lx = ly = 0;
     return true;
   }
-  const int per = fm.tileW * fm.tileH;
-  tileK = (int)(slot / per);
-  const int rem = (int)(slot % per);
-  const int t = fm.shardIndex + tileK * fm.shardCount;
-  const int tx = t % fm.tilesX, ty = t / fm.tilesX;
-  const int blk = rem >> 6, in = rem & 63;
-  const int bpr = fm.tileW >> 3;
-  lx = (blk % bpr) * 8 + (in & 7);
-  ly = (blk / bpr) * 8 + (in >> 3);
+  const unsigned int u = base.rem + rel;                  // < 2^31: a batch has fewer than 2^30 samples
+  const unsigned int dk = fastDiv(u, fm.dPer);
+  const int rem = (int)(u - dk * fm.dPer.d);
+  tileK = base.tile + (int)dk;
+  const unsigned int t = (unsigned int)(fm.shardIndex + tileK * fm.shardCount);
+  const unsigned int ty = fastDiv(t, fm.dTilesX);
+  const int tx = (int)(t - ty * fm.dTilesX.d);
+  const unsigned int blk = (unsigned int)(rem >> 6);
+  const int in = rem & 63;
+  const unsigned int by = fastDiv(blk, fm.dBlocksPerRow);
+  const int bx = (int)(blk - by * fm.dBlocksPerRow.d);
+  lx = bx * 8 + (in & 7);
+  ly = (int)by * 8 + (in >> 3);
   x = tx * fm.tileW + lx;
-  y = ty * fm.tileH + ly;
+  y = (int)ty * fm.tileH + ly;
   return x < fm.width && y < fm.height;
 }
 
@@ -149,25 +198,25 @@ struct RaySrc {
   size_t stride;
   int primary;            // 1: level 0
   FrameMap fm;
-  long long firstSlot;    // pixel slot of sample 0 of the batch
+  SlotBase first;         // pixel slot of sample 0 of the batch
 };
 
 // Camera::rayThrough (camera.cpp:20-31) at the coordinates of tracePixel /
 // tracePixelAntiAlias (RayTracer.cpp:51-52,84-92) for sample i of the batch.
 // Returns the ray type, -1 for a sample of a pixel slot outside the frame.
-__device__ __forceinline__ int primaryRay(const DevScene& S, const FrameMap& fm, long long firstSlot, int i,
+__device__ __forceinline__ int primaryRay(const DevScene& S, const FrameMap& fm, const SlotBase& first, int i,
                                           V3& p, V3& dir) {
-  const long long slot = firstSlot + i / fm.ns;
-  const int k = i % fm.ns;
+  const unsigned int rel = fastDiv((unsigned int)i, fm.dNs);
+  const int k = (int)((unsigned int)i - rel * fm.dNs.d);
   int px, py, tk, lx, ly;
-  if (!slotToPixel(fm, slot, px, py, tk, lx, ly)) return -1;
+  if (!slotToPixel(fm, first, rel, px, py, tk, lx, ly)) return -1;
   double x = double(px) / double(fm.width);
   double y = double(py) / double(fm.height);
   if (fm.aaN > 0) {
     const int n = fm.aaN;
     const double deltaX = (1.0 / double(fm.width)) / n;
     const double deltaY = (1.0 / double(fm.height)) / n;
-    const int sc = k / n, sr = k % n;   // column outer, row inner (RayTracer.cpp:87-89)
+    const int sc = (int)fastDiv((unsigned int)k, fm.dAaN), sr = k - sc * n;   // column outer, row inner (RayTracer.cpp:87-89)
     const double jx = fm.jitter ? fm.jitter[2 * k] : 0.0, jy = fm.jitter ? fm.jitter[2 * k + 1] : 0.0;
     x = x + sc * deltaX + jx * deltaX;
     y = y + sr * deltaY + jy * deltaY;
@@ -181,7 +230,7 @@ __device__ __forceinline__ int primaryRay(const DevScene& S, const FrameMap& fm,
 
 // Ray i of the level; returns its type (< 0: no ray in this slot).
 __device__ __forceinline__ int rayOf(const DevScene& S, const RaySrc& R, int i, V3& p, V3& d) {
-  if (R.primary) return primaryRay(S, R.fm, R.firstSlot, i, p, d);
+  if (R.primary) return primaryRay(S, R.fm, R.first, i, p, d);
   const int type = R.type[i];
   if (type >= 0) {
     p = loadV3(R.p, R.stride, i);
@@ -742,7 +791,7 @@ k_combine(DevScene S, size_t spOff, int nsp, Pool P) {
 constexpr int kResolveSamples = 2048;   // LDS rows * pitch per colour channel
 
 __global__ void __launch_bounds__(kBlock)
-k_resolve(FrameMap fm, long long firstPixelSlot, int nPixels, int ppb, Pool P, unsigned char* rgb, int* hitId,
+k_resolve(FrameMap fm, SlotBase first, int nPixels, int ppb, Pool P, unsigned char* rgb, int* hitId,
           const long long* tileOffset) {
   __shared__ double lds[3][kResolveSamples + kBlock];
   __shared__ int ldsId[kBlock];
@@ -758,7 +807,7 @@ k_resolve(FrameMap fm, long long firstPixelSlot, int nPixels, int ppb, Pool P, u
     if (c.y > 1) c.y = 1.0;
     if (c.z < 0) c.z = 0.0;
     if (c.z > 1) c.z = 1.0;
-    const int pl = e / ns, k = e - pl * ns;
+    const int pl = (int)fastDiv((unsigned int)e, fm.dNs), k = e - pl * ns;
     const int o = pl * pitch + k;
     lds[0][o] = c.x;
     lds[1][o] = c.y;
@@ -768,9 +817,9 @@ k_resolve(FrameMap fm, long long firstPixelSlot, int nPixels, int ppb, Pool P, u
   __syncthreads();
   const int pl = threadIdx.x;
   if (pl >= npix) return;
-  const long long slot = firstPixelSlot + pix0 + pl;
+  const unsigned int rel = (unsigned int)(pix0 + pl);
   int px, py, tk, lx, ly;
-  if (!slotToPixel(fm, slot, px, py, tk, lx, ly)) return;
+  if (!slotToPixel(fm, first, rel, px, py, tk, lx, ly)) return;
   V3 col(0, 0, 0);
   const int r = pl * pitch;
   if (fm.aaN > 0) {
@@ -782,10 +831,10 @@ k_resolve(FrameMap fm, long long firstPixelSlot, int nPixels, int ppb, Pool P, u
   }
   size_t o;
   if (fm.pixelList && fm.listOutput) {
-    o = (size_t)slot;
+    o = (size_t)(first.slot + rel);
   } else if (tileOffset) {
-    const int t = fm.shardIndex + tk * fm.shardCount;
-    const int tx = t % fm.tilesX;
+    const unsigned int t = (unsigned int)(fm.shardIndex + tk * fm.shardCount);
+    const int tx = (int)(t - fastDiv(t, fm.dTilesX) * fm.dTilesX.d);
     const int wt = min(fm.tileW, fm.width - tx * fm.tileW);
     o = (size_t)tileOffset[tk] + (size_t)ly * wt + lx;
   } else {
@@ -833,11 +882,11 @@ __global__ void __launch_bounds__(kBlock)
 k_unpack(const unsigned char* packed, int bpp, FrameMap fm, const long long* tileOffset, int nTiles,
          unsigned char* frame) {
   const long long slot = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (slot >= (long long)nTiles * fm.tileW * fm.tileH) return;
+  if (slot >= (long long)nTiles * fm.tileW * fm.tileH) return;   // < 2^31, checked by the caller
   int px, py, tk, lx, ly;
-  if (!slotToPixel(fm, slot, px, py, tk, lx, ly)) return;
-  const int t = fm.shardIndex + tk * fm.shardCount;
-  const int tx = t % fm.tilesX;
+  if (!slotToPixel(fm, SlotBase{0, 0, 0u}, (unsigned int)slot, px, py, tk, lx, ly)) return;
+  const unsigned int t = (unsigned int)(fm.shardIndex + tk * fm.shardCount);
+  const int tx = (int)(t - fastDiv(t, fm.dTilesX) * fm.dTilesX.d);
   const int wt = min(fm.tileW, fm.width - tx * fm.tileW);
   const size_t src = (size_t)tileOffset[tk] + (size_t)ly * wt + lx;
   const size_t dst = (size_t)px + (size_t)py * fm.width;
@@ -1212,7 +1261,7 @@ int renderBatch(RenderCtx& cx, long long first, int count, long long* slotsUsed)
     R.p = P.rayP[par]; R.d = P.rayD[par]; R.type = P.rayType[par]; R.stride = P.cap;
     R.primary = level == 0 ? 1 : 0;
     R.fm = cx.fm;
-    R.firstSlot = first;
+    R.first = makeSlotBase(cx.fm, first);
     const bool timed = timedBegin(sc, sc->stream);
     if (cx.fast) { if (cx.wantStats) launchTrace<true, true>(sc, P, n, R); else launchTrace<true, false>(sc, P, n, R); }
     else { if (cx.wantStats) launchTrace<false, true>(sc, P, n, R); else launchTrace<false, false>(sc, P, n, R); }
@@ -1276,7 +1325,7 @@ int renderBatch(RenderCtx& cx, long long first, int count, long long* slotsUsed)
   {
     const int pitch = ns | 1;
     const int ppb = std::max(1, std::min(kBlock, kResolveSamples / pitch));
-    k_resolve<<<(count + ppb - 1) / ppb, kBlock, 0, sc->stream>>>(cx.fm, first, count, ppb, P, cx.rgbDev,
+    k_resolve<<<(count + ppb - 1) / ppb, kBlock, 0, sc->stream>>>(cx.fm, makeSlotBase(cx.fm, first), count, ppb, P, cx.rgbDev,
                                                                     cx.hitDev, cx.tileOffDev);
   }
   HIP_TRY(hipGetLastError());
@@ -1831,6 +1880,7 @@ int rt_render(RtScene* sc, const RtRenderParams* rp, unsigned char* rgb8_out, in
   fm.ns = (rp->aa_mode == RT_AA_FULL) ? nsFull : 1;
   fm.aaN = (rp->aa_mode == RT_AA_FULL) ? rp->aa_samples : 0;
   fm.jitter = (rp->aa_mode != RT_AA_NONE && rp->jitter) ? sc->jitterDev : nullptr;
+  setDivisors(fm);
 
   sc->eventsUsed = 0;
   HIP_TRY(hipEventRecord(sc->evStart, sc->stream));
@@ -1860,6 +1910,7 @@ int rt_render(RtScene* sc, const RtRenderParams* rp, unsigned char* rgb8_out, in
       fm.pixelList = listDev;
       fm.ns = nsFull;
       fm.aaN = rp->aa_samples;
+      setDivisors(fm);
       int* keepHit = cx.hitDev;
       cx.hitDev = nullptr;  // the base pass already recorded the primary hits
       const long long nFlag = (long long)flagged.size() / 2;
@@ -1964,6 +2015,7 @@ int rt_render_pixels(RtScene* sc, const RtRenderParams* rp, int n_pixels, const 
   fm.ns = ns;
   fm.aaN = (rp->aa_mode == RT_AA_NONE) ? 0 : rp->aa_samples;
   fm.jitter = (rp->aa_mode != RT_AA_NONE && rp->jitter) ? sc->jitterDev : nullptr;
+  setDivisors(fm);
   sc->eventsUsed = 0;
   HIP_TRY(hipEventRecord(sc->evStart, sc->stream));
   rc = renderRange(cx, 0, n_pixels);
@@ -2023,7 +2075,9 @@ int rt_unpack_tiles(const unsigned char* packed_dev, int bytes_per_pixel, int wi
   std::memset(&fm, 0, sizeof fm);
   fm.width = width; fm.height = height; fm.tileW = tile_w; fm.tileH = tile_h; fm.tilesX = TL.tilesX;
   fm.shardIndex = shard_index; fm.shardCount = shard_count; fm.ns = 1;
+  setDivisors(fm);
   const long long slots = (long long)TL.nTiles * tile_w * tile_h;
+  if (slots >= (1ll << 31)) return fail(RT_ERR_UNSUPPORTED, "frame too large for one unpack launch");
   k_unpack<<<gridFor(slots), kBlock, 0, st>>>(packed_dev, bytes_per_pixel, fm, off, TL.nTiles, frame_dev);
   HIP_TRY(hipGetLastError());
   return RT_OK;   // stream-ordered: the caller synchronises hip_stream
