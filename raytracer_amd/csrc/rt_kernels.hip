@@ -639,7 +639,10 @@ __device__ __forceinline__ void shadePoint(const DevScene& S, const Pool& P, int
       const V3 sinVector = cosVector - L;
       const V3 refl = normalized(cosVector + sinVector);
       const double c = dot(refl, view);
-      I = I + prod(ks, lightIntensity) * pow((c < 0.0) ? 0.0 : c, shin);
+      const double base = (c < 0.0) ? 0.0 : c;
+      // pow(0, y) is 0 for y > 0: the highlight's far side needs no pow
+      const double spec = (base == 0.0 && shin > 0.0) ? 0.0 : pow(base, shin);
+      I = I + prod(ks, lightIntensity) * spec;
     }
   }
   storeV3(P.spShade, P.cap, g, I);
