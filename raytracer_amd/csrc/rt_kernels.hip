@@ -515,8 +515,8 @@ __device__ __forceinline__ void shadowQuery(const DevScene& S, const RtLight& l,
 // distanceAttenuation * shadowAttenuation of one light (material.cpp:59-60,
 // light.cpp:14-149) from the outcome of its shadow query, and the direction L
 // to the light as Material::shade normalises it.
-__device__ __forceinline__ V3 lightIntensityFrom(const DevScene& S, const RtLight& l, const V3& Q, int prim, double th,
-                                                 bool anyOccluder, V3& L) {
+__device__ __forceinline__ V3 lightIntensityFrom(const DevScene& S, const RtLight& l, const double* cone, const V3& Q,
+                                                 int prim, double th, bool anyOccluder, V3& L) {
   const V3 color(l.color);
   V3 atten;
   if (l.type == RT_LIGHT_DIRECTIONAL) {
@@ -551,11 +551,18 @@ __device__ __forceinline__ V3 lightIntensityFrom(const DevScene& S, const RtLigh
     } else {
       sd = sd * -1;
       const V3 orientation(l.orientation);
-      const double angle = acos(dot(orientation, sd)) * 180 / M_PI;
-      if (angle > l.atten_angle) {
+      const double x = dot(orientation, sd);
+      // acos is decreasing: x below cone[0] is outside the cone, x above cone[1]
+      // (and at most 1: acos of more is NaN, which compares false) inside it; a
+      // NaN x fails both tests and takes the reference's own expression
+      bool outside;
+      if (x < cone[0] && x >= -1.0) outside = true;
+      else if (x > cone[1] && x <= 1.0) outside = false;
+      else outside = acos(x) * 180 / M_PI > l.atten_angle;
+      if (outside) {
         atten = V3(0.0, 0.0, 0.0);
       } else {
-        const double fallFactor = pow(dot(orientation, sd), l.fall_rate);
+        const double fallFactor = pow(x, l.fall_rate);
         atten = occluded ? prod((color * fallFactor), kt) : (color * fallFactor);
       }
     }
@@ -621,8 +628,8 @@ __device__ __forceinline__ void shadePoint(const DevScene& S, const Pool& P, int
     const int sp = P.shPrim[o];
     const double th = P.shT ? P.shT[o] : 0.0;
     V3 L;
-    const V3 lightIntensity = lightIntensityFrom(S, S.lights[li], Q, sp == RT_PRIM_ANY ? RT_PRIM_NONE : sp, th,
-                                                 sp == RT_PRIM_ANY, L);
+    const V3 lightIntensity = lightIntensityFrom(S, S.lights[li], S.spotCone + 2 * li, Q,
+                                                 sp == RT_PRIM_ANY ? RT_PRIM_NONE : sp, th, sp == RT_PRIM_ANY, L);
     // A light that contributes exactly zero (occluded by an opaque surface,
     // outside a spot cone) adds +0 to every component when the Phong factors are
     // finite: skip their sqrt / pow.  A NaN shade point (the hit of a NaN ray)
@@ -1718,6 +1725,20 @@ int rt_scene_create(const RtSceneDesc* d, RtScene** out) {
   { RtMesh* p; HIP_TRY(upload(d->meshes, (size_t)d->n_meshes, &p)); keep(p); D.meshes = p; }
   { RtMaterial* p; HIP_TRY(upload(d->materials, (size_t)d->n_materials, &p)); keep(p); D.materials = p; }
   { RtLight* p; HIP_TRY(upload(d->lights, (size_t)d->n_lights, &p)); keep(p); D.lights = p; }
+  {
+    std::vector<double> cone(2 * (size_t)std::max(1, d->n_lights), 0.0);
+    for (int li = 0; li < d->n_lights; li++) {
+      // outside: angle > atten + hair  <=>  x < cos(that); inside: angle < atten - hair.
+      // The hair (1.7e-11 rad) is far above the rounding of cos and acos as long
+      // as the cone's edge is not within 0.01 degrees of 0 or 180, where acos is
+      // steep; such cones (and angles outside [0, 180]) keep the acos for every x.
+      const double a = d->lights[li].atten_angle, hair = 1e-9;
+      const bool plain = a > 0.01 && a < 179.99;
+      cone[2 * li] = plain ? std::cos((a + hair) * M_PI / 180.0) : -2.0;
+      cone[2 * li + 1] = plain ? std::cos((a - hair) * M_PI / 180.0) : 2.0;
+    }
+    double* p; HIP_TRY(upload(cone.data(), cone.size(), &p)); keep(p); D.spotCone = p;
+  }
   {
     std::vector<DevMat> dm((size_t)d->n_materials);
     for (int m = 0; m < d->n_materials; m++) {

@@ -104,6 +104,11 @@ struct DevScene {
   const RtMesh* meshes;
   const RtMaterial* materials;
   const RtLight* lights;
+  // per light: cos(atten_angle + 1e-9 deg), cos(atten_angle - 1e-9 deg).  A spot
+  // light's cone test acos(x) * 180 / pi > atten_angle (light.cpp:129-133,141-145)
+  // is decided by x against these two wherever x is not within that hair of the
+  // cone's edge; only there is the acos itself needed.
+  const double* spotCone;
   const double* vnormals;    // 3 per global vertex
   const double* face_normals;  // 9 per face: the vertex normals of its corners (NULL: none / flat shading)
   const int* faceInfo;         // RT_FI_* word per face: what a hit needs to know about its mesh and owner
