@@ -623,6 +623,8 @@ __device__ __forceinline__ void shadePoint(const DevScene& S, const Pool& P, int
     I = V3(dm.base);
   }
   const bool hasKd = !iszero(kd), hasKs = !iszero(ks);
+  // the same for every light (material.cpp:66-67)
+  const V3 view = hasKs ? normalized(V3(S.eye) - Q) : V3(0.0, 0.0, 0.0);
   for (int li = 0; li < S.n_lights; li++) {
     const size_t o = (size_t)li * P.cap + s;
     const int sp = P.shPrim[o];
@@ -641,7 +643,6 @@ __device__ __forceinline__ void shadePoint(const DevScene& S, const Pool& P, int
       I = I + prod(kd, lightIntensity) * ((c < 0.0) ? 0.0 : c);
     }
     if (hasKs) {
-      const V3 view = normalized(V3(S.eye) - Q);             // material.cpp:66-67
       const V3 cosVector = N * dot(L, N);
       const V3 sinVector = cosVector - L;
       const V3 refl = normalized(cosVector + sinVector);
