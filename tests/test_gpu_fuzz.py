@@ -203,3 +203,63 @@ def test_random_mesh_only_scene_in_small_batches_and_shards(built, seed):
     ds.close()
     common.assert_parity(frame, fhits, lr, lh, what="seed %d %s, fast traversal in shards vs linear scan" % (seed, opts))
     assert tuple(total) == _counts(ls)
+
+
+def _hit_arrays(hits):
+    """(values[n, 7] = t, N, bary; ids[n]) of an RtHit array."""
+    raw = np.frombuffer(hits, dtype=np.uint8).reshape(len(hits), -1)
+    vals = np.ascontiguousarray(raw[:, :56]).view(np.float64).reshape(len(hits), 7)
+    ids = np.ascontiguousarray(raw[:, 56:60]).view(np.int32).reshape(len(hits))
+    return vals, ids
+
+
+def _same(a, b):
+    """== with NaN equal to NaN (the sign and payload of a NaN are the hardware's)."""
+    return (a == b) | (np.isnan(a) & np.isnan(b))
+
+
+@pytest.mark.parametrize("seed", range(max(6, N_SEEDS // 4)))
+def test_random_rays_on_random_scenes_bit_exact(built, seed):
+    """Scene::intersect on 3000 rays per scene -- random, axis-parallel, starting
+    on and inside objects, with NaN directions and NaN origins, of every ray type:
+    object id, t, N and barycentrics compared with ==.  REFERENCE traversal
+    against the oracle on the same scene, FAST against its linear scan."""
+    text, opts = random_scene(seed) if seed % 2 == 0 else random_mesh_scene(seed)
+    opts = {k: v for k, v in opts.items()}
+    rng = np.random.RandomState(900 + seed)
+    hs = host.HostScene(text=text, **opts)
+    lin = host.HostScene(text=text, **dict(opts, kd_tree=False))
+    ds = device.DeviceScene(hs.desc_ptr)
+    n = 3000
+    p = rng.uniform(-4, 4, size=(n, 3)) + np.array([0.0, 2.0, 0.5])
+    tgt = rng.uniform(-3, 3, size=(n, 3)) + np.array([0.0, 1.0, 0.5])
+    d = tgt - p
+    zero = rng.randint(0, 16, size=n)           # one row in two gets zero components
+    for a in range(3):
+        d[((zero >> a) & 1 == 1) & (zero < 8), a] = 0.0
+    d[np.all(d == 0.0, axis=1)] = np.array([0.0, -1.0, 0.0])
+    d /= np.linalg.norm(d, axis=1)[:, None]
+    rays = np.concatenate([p, d], axis=1)
+    # second bounces: rays that start exactly on what the first batch hit
+    first = loader.intersect_batch(lin.desc_ptr, rays)
+    t = np.array([h.t for h in first])
+    hit = np.array([h.object_id != 0 for h in first])
+    q = p + t[:, None] * d
+    nd = rng.normal(size=(n, 3))
+    nd /= np.linalg.norm(nd, axis=1)[:, None]
+    bounce = np.concatenate([q, nd], axis=1)[hit][:1000]
+    nan_d = rays[:200].copy()
+    nan_d[:, 3:] = np.nan
+    nan_p = rays[200:300].copy()
+    nan_p[:, :3] = np.nan
+    rays = np.concatenate([rays, bounce, nan_d, nan_p], axis=0)
+    types = rng.choice([abi.RT_RAY_VISIBILITY, abi.RT_RAY_REFLECTION, abi.RT_RAY_REFRACTION, abi.RT_RAY_SHADOW],
+                       size=len(rays)).astype(np.int32)
+    for trav, scene in ((abi.RT_TRAVERSE_REFERENCE, hs), (abi.RT_TRAVERSE_FAST, lin)):
+        ref = loader.intersect_batch(scene.desc_ptr, rays, types)
+        got = ds.intersect(rays, types, trav)
+        (gv, gi), (rv, ri) = _hit_arrays(got), _hit_arrays(ref)
+        bad = np.nonzero(~(_same(gv, rv).all(axis=1) & (gi == ri)))[0]
+        assert len(bad) == 0, (trav, len(bad), [(int(k), list(rays[k]), got[k].object_id, ref[k].object_id,
+                                                 got[k].t, ref[k].t) for k in bad[:4]])
+    ds.close()
