@@ -131,7 +131,10 @@ def main():
 
     hs, width, height, kw, desc = build_scene(args.config, args.scale)
     trav = abi.RT_TRAVERSE_FAST if args.traversal == "fast" else abi.RT_TRAVERSE_REFERENCE
+    t_create = time.perf_counter()
     ds = device.DeviceScene(hs.desc_ptr)
+    if rank == 0:
+        log("[bench] rt_scene_create (validation, upload, BVH build): %.2f s" % (time.perf_counter() - t_create))
     pad_px = parallel.max_shard_pixels(width, height, TILE, TILE, world)
     # Two packed buffers, used in turn: the gather of frame k may still read its
     # buffer on the backend's stream while the library renders frame k+1 on its
