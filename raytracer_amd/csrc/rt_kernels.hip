@@ -576,13 +576,14 @@ __device__ __forceinline__ V3 lightIntensityFrom(const DevScene& S, const RtLigh
 // the wavefronts that hide the traversal's memory latency).
 template <bool FAST, bool STATS, bool TRI>
 __global__ void __launch_bounds__(kTraceBlock) RT_TRACE_ATTR
-k_shadow(DevScene S, long long nMax, size_t spOff, Pool P) {
-  const long long idx = xcdBlock() * blockDim.x + threadIdx.x;
+k_shadow(DevScene S, int nMax, size_t spOff, Pool P) {
+  // grid: x over the shade points of the level (at most nMax), y = light
+  const long long sIdx = xcdBlock() * blockDim.x + threadIdx.x;
   const unsigned int nsp = P.counters->nsp;
   TraceCounters tc{0, 0};
-  if (idx < nMax && idx < (long long)nsp * S.n_lights) {
-    const int li = (int)(idx / nsp);
-    const int s = (int)(idx % nsp);
+  if (sIdx < nMax && sIdx < (long long)nsp) {
+    const int li = (int)blockIdx.y;
+    const int s = (int)sIdx;
     if ((unsigned int)P.spMat[spOff + s] & RT_SPM_LIT) {
       const V3 Q = loadV3(P.spQ, P.cap, spOff + s);
       int prim;
@@ -1208,12 +1209,12 @@ void launchTrace(RtScene* sc, const Pool& P, int n, const RaySrc& R) {
     k_trace<FAST, STATS, false><<<blocks, kTraceBlock, 0, sc->stream>>>(sc->dev, n, R, P.hitT, P.hitPrim, P.counters);
 }
 template <bool FAST, bool STATS>
-void launchShadow(RtScene* sc, hipStream_t st, const Pool& P, long long nMax, size_t spOff) {
-  const int blocks = (int)((nMax + kTraceBlock - 1) / kTraceBlock);
+void launchShadow(RtScene* sc, hipStream_t st, const Pool& P, int nMax, size_t spOff) {
+  const dim3 grid((unsigned int)(((long long)nMax + kTraceBlock - 1) / kTraceBlock), (unsigned int)sc->dev.n_lights);
   if (FAST && sc->triOnly)
-    k_shadow<FAST, STATS, true><<<blocks, kTraceBlock, 0, st>>>(sc->dev, nMax, spOff, P);
+    k_shadow<FAST, STATS, true><<<grid, kTraceBlock, 0, st>>>(sc->dev, nMax, spOff, P);
   else
-    k_shadow<FAST, STATS, false><<<blocks, kTraceBlock, 0, st>>>(sc->dev, nMax, spOff, P);
+    k_shadow<FAST, STATS, false><<<grid, kTraceBlock, 0, st>>>(sc->dev, nMax, spOff, P);
 }
 
 bool timedBegin(RtScene* sc, hipStream_t st) {
@@ -1291,11 +1292,10 @@ int renderBatch(RenderCtx& cx, long long first, int count, long long* slotsUsed)
       HIP_TRY(hipEventRecord(sc->evSurface, sc->stream));
       HIP_TRY(hipStreamWaitEvent(sc->side, sc->evSurface, 0));
     }
-    const long long shadowThreads = (long long)n * sc->dev.n_lights;
-    if (shadowThreads > 0) {
+    if (sc->dev.n_lights > 0) {
       const bool timed2 = timedBegin(sc, lightStream);
-      if (cx.fast) { if (cx.wantStats) launchShadow<true, true>(sc, lightStream, P, shadowThreads, spOff); else launchShadow<true, false>(sc, lightStream, P, shadowThreads, spOff); }
-      else { if (cx.wantStats) launchShadow<false, true>(sc, lightStream, P, shadowThreads, spOff); else launchShadow<false, false>(sc, lightStream, P, shadowThreads, spOff); }
+      if (cx.fast) { if (cx.wantStats) launchShadow<true, true>(sc, lightStream, P, n, spOff); else launchShadow<true, false>(sc, lightStream, P, n, spOff); }
+      else { if (cx.wantStats) launchShadow<false, true>(sc, lightStream, P, n, spOff); else launchShadow<false, false>(sc, lightStream, P, n, spOff); }
       if (timed2) timedEnd(sc, lightStream, 1);
       cx.stats.lights_launches++;
     }
@@ -1461,6 +1461,7 @@ int rt_scene_create(const RtSceneDesc* d, RtScene** out) {
   if (d->n_objects < 0 || d->n_lights < 0 || d->n_meshes < 0 || d->n_faces < 0 || d->n_nodes < 0 ||
       d->n_materials < 0 || d->n_vertices < 0 || d->n_leaf_items < 0)
     return fail(RT_ERR_INVALID, "negative count in scene description");
+  if (d->n_lights > 65535) return fail(RT_ERR_UNSUPPORTED, "more than 65535 lights");   // the shadow kernel's grid has one row per light
   // ---- validate indices so that no kernel can read out of bounds
   for (int i = 0; i < d->n_objects; i++) {
     const RtObject& o = d->objects[i];
