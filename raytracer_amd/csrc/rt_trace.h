@@ -856,12 +856,28 @@ __device__ int traceBvh(const DevScene& S, const V3& p, const V3& d, int rayType
     }
     return RT_PRIM_NONE;
   }
-  {
-    double t0, t1;
-    if (!boxIntersect(S.bvh_bb_min, S.bvh_bb_max, p, d, t0, t1)) return RT_PRIM_NONE;
-  }
   BvhRay r;
   bvhRaySetup(S, p, d, rayType, r);
+  {
+    // Early out for rays that pass the whole structure by (sky): slabs of the
+    // root box with the reciprocals the setup has made anyway, widened so that
+    // rounding can only let a ray through, never turn one away.  An axis whose
+    // products are NaN (0 * inf: origin on a face, direction parallel to it)
+    // constrains nothing.
+    const double kInfD = __longlong_as_double(0x7ff0000000000000LL);
+    double t0 = -kInfD, t1 = kInfD;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      const double lo = (S.bvh_bb_min[a] - p.get(a)) * r.inv.get(a);
+      const double hi = (S.bvh_bb_max[a] - p.get(a)) * r.inv.get(a);
+      const bool ok = (lo == lo) & (hi == hi);
+      const double n = lo < hi ? lo : hi, f = lo < hi ? hi : lo;
+      t0 = (ok & (n > t0)) ? n : t0;
+      t1 = (ok & (f < t1)) ? f : t1;
+    }
+    const double slack = 1.0e-9 * (1.0 + fabs(t0) + fabs(t1));
+    if (t0 > t1 + slack || t1 < -slack) return RT_PRIM_NONE;
+  }
   bool haveOne = false;
   double bestT = tLimit;   // doubles as the far cull bound until a hit exists
   float bestTf = roundUpF(bestT);
