@@ -643,6 +643,11 @@ __device__ __forceinline__ void bvhRaySetup(const DevScene& S, const V3& p, cons
   r.negx = (d.x < 0.0) & !r.zx;
   r.negy = (d.y < 0.0) & !r.zy;
   r.negz = (d.z < 0.0) & !r.zz;
+}
+
+// The rest of the setup, for rays that get past the root box: what the
+// triangle tests need.
+__device__ __forceinline__ void bvhRaySetupLocal(const V3& p, const V3& d, BvhRay& r) {
   const V3 dirI = (p + d) - p;
   r.lenI = length(dirI);
   r.ldI = V3(dirI.x / r.lenI, dirI.y / r.lenI, dirI.z / r.lenI);
@@ -878,6 +883,7 @@ __device__ int traceBvh(const DevScene& S, const V3& p, const V3& d, int rayType
     const double slack = 1.0e-9 * (1.0 + fabs(t0) + fabs(t1));
     if (t0 > t1 + slack || t1 < -slack) return RT_PRIM_NONE;
   }
+  bvhRaySetupLocal(p, d, r);
   bool haveOne = false;
   double bestT = tLimit;   // doubles as the far cull bound until a hit exists
   float bestTf = roundUpF(bestT);
