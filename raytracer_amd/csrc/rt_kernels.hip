@@ -134,6 +134,9 @@ struct FrameMap {           // pixel slot -> pixel, for tile-ordered rendering
   int aaN;                  // n (ns = n*n) or 0
   const double* jitter;     // device copy, 2*ns values or NULL
   FastDiv dPer, dTilesX, dBlocksPerRow, dNs, dAaN;   // by tileW*tileH, tilesX, tileW/8, ns, aaN (setDivisors)
+  // sub-sample pitch of tracePixelAntiAlias (RayTracer.cpp:84-85), the same for
+  // every sample: divided once on the host (IEEE division, the same bits)
+  double deltaX, deltaY;
 };
 
 // Fills the divisors from the sizes above (after every change of those).
@@ -143,6 +146,9 @@ inline void setDivisors(FrameMap& fm) {
   fm.dBlocksPerRow = makeFastDiv((unsigned int)(fm.tileW >> 3));
   fm.dNs = makeFastDiv((unsigned int)fm.ns);
   fm.dAaN = makeFastDiv((unsigned int)std::max(1, fm.aaN));
+  const int n = std::max(1, fm.aaN);
+  fm.deltaX = (1.0 / double(fm.width)) / n;
+  fm.deltaY = (1.0 / double(fm.height)) / n;
 }
 
 // Where a batch (or a launch) starts in the slot order, split on the host so
@@ -214,8 +220,7 @@ __device__ __forceinline__ int primaryRay(const DevScene& S, const FrameMap& fm,
   double y = double(py) / double(fm.height);
   if (fm.aaN > 0) {
     const int n = fm.aaN;
-    const double deltaX = (1.0 / double(fm.width)) / n;
-    const double deltaY = (1.0 / double(fm.height)) / n;
+    const double deltaX = fm.deltaX, deltaY = fm.deltaY;
     const int sc = (int)fastDiv((unsigned int)k, fm.dAaN), sr = k - sc * n;   // column outer, row inner (RayTracer.cpp:87-89)
     const double jx = fm.jitter ? fm.jitter[2 * k] : 0.0, jy = fm.jitter ? fm.jitter[2 * k + 1] : 0.0;
     x = x + sc * deltaX + jx * deltaX;
