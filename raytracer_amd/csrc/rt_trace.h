@@ -863,7 +863,7 @@ __device__ int traceBvh(const DevScene& S, const V3& p, const V3& d, int rayType
   }
   BvhRay r;
   bvhRaySetup(S, p, d, rayType, r);
-  {
+  if (rayType == RT_RAY_VISIBILITY) {   // every other ray starts on a surface, inside the box
     // Early out for rays that pass the whole structure by (sky): slabs of the
     // root box with the reciprocals the setup has made anyway, widened so that
     // rounding can only let a ray through, never turn one away.  An axis whose
