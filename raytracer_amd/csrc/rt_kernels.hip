@@ -675,6 +675,10 @@ k_lights(DevScene S, int nMax, size_t spOff, Pool P) {
 
 // The secondary rays of RayTracer::traceRay (RayTracer.cpp:152-201).  Reflected rays of a tile are
 // queued before its refracted rays.
+// REFR false: no material of the scene transmits (DevScene::opaque), so the
+// refraction code -- acos, a second queue class -- is left out; it costs this
+// latency-bound kernel a third of its resident wavefronts even when it never runs.
+template <bool REFR>
 __global__ void __launch_bounds__(kBlock)
 k_shade(DevScene S, int nMax, int items, int par, RaySrc R, size_t spOff, size_t rayOff, size_t nextRayOff,
         int depthLeft, Pool P) {
@@ -696,7 +700,7 @@ k_shade(DevScene S, int nMax, int items, int par, RaySrc R, size_t spOff, size_t
       if (mw & RT_SPM_LIT) myLit++;
       if (depthLeft > 0) {
         wantRefl = interp ? !iszero(loadV3(P.spKr, P.cap, g)) : (dm->flags & RT_MATF_KR) != 0;
-        if (interp ? !iszero(loadV3(P.spKt, P.cap, g)) : (dm->flags & RT_MATF_KT) != 0) {
+        if (REFR && (interp ? !iszero(loadV3(P.spKt, P.cap, g)) : (dm->flags & RT_MATF_KT) != 0)) {
           V3 p, d;
           rayOf(S, R, (int)((size_t)P.spRayGlobal[g] - rayOff), p, d);
           const double cosineAngle = acos(dot(loadV3(P.spN, P.cap, g), d)) * 180 / M_PI;
@@ -710,11 +714,11 @@ k_shade(DevScene S, int nMax, int items, int par, RaySrc R, size_t spOff, size_t
     reflMask |= (wantRefl ? 1u : 0u) << k;
     refrMask |= (wantRefr ? 1u : 0u) << k;
     tileCount(ts, 0, k, wantRefl);
-    tileCount(ts, 1, k, wantRefr);
+    if (REFR) tileCount(ts, 1, k, wantRefr);
   }
   if (threadIdx.x == 0) litCount = 0;
   unsigned int nRefl = 0, nRefr = 0;
-  tileReserve(ts, items, 2, &P.counters->nnext, nRefl, nRefr);   // has barriers before and after the scan
+  tileReserve(ts, items, REFR ? 2 : 1, &P.counters->nnext, nRefl, nRefr);   // has barriers before and after the scan
   if (myLit) atomicAdd(&litCount, myLit);                         // LDS atomic
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -727,9 +731,9 @@ k_shade(DevScene S, int nMax, int items, int par, RaySrc R, size_t spOff, size_t
   const int np = par ^ 1;
   for (int k = 0; k < items; k++) {
     const int s = tileBase + k * kBlock + threadIdx.x;
-    const bool wantRefl = (reflMask >> k) & 1u, wantRefr = (refrMask >> k) & 1u;
+    const bool wantRefl = (reflMask >> k) & 1u, wantRefr = REFR && ((refrMask >> k) & 1u);
     const unsigned int a = tileSlot(ts, 0, k, wantRefl);
-    const unsigned int b = tileSlot(ts, 1, k, wantRefr);
+    const unsigned int b = REFR ? tileSlot(ts, 1, k, wantRefr) : 0u;
     if ((unsigned int)s >= nsp) continue;
     const size_t g = spOff + s;
     int childRefl = -1, childRefr = -1;
@@ -1309,8 +1313,12 @@ int renderBatch(RenderCtx& cx, long long first, int count, long long* slotsUsed)
       HIP_TRY(hipEventRecord(sc->evSide, sc->side));
       sidePending = true;
     }
-    k_shade<<<tiles, kBlock, 0, sc->stream>>>(sc->dev, n, items, par, R, spOff, rayOff, rayOff + n,
-                                              rp.depth - level, P);
+    if (sc->dev.opaque)
+      k_shade<false><<<tiles, kBlock, 0, sc->stream>>>(sc->dev, n, items, par, R, spOff, rayOff, rayOff + n,
+                                                       rp.depth - level, P);
+    else
+      k_shade<true><<<tiles, kBlock, 0, sc->stream>>>(sc->dev, n, items, par, R, spOff, rayOff, rayOff + n,
+                                                      rp.depth - level, P);
     HIP_TRY(hipMemcpyAsync(sc->countersHost, P.counters, sizeof(Counters), hipMemcpyDeviceToHost, sc->stream));
     HIP_TRY(hipStreamSynchronize(sc->stream));
     const Counters c = *sc->countersHost;
