@@ -809,7 +809,7 @@ k_combine(DevScene S, size_t spOff, int nsp, Pool P) {
 // (row pitch odd, so the column walk below is free of bank conflicts); then
 // one thread per pixel adds its ns samples in sample order, as the reference's
 // loop does.
-constexpr int kResolveSamples = 2048;   // LDS rows * pitch per colour channel
+constexpr int kResolveSamples = 1024;   // LDS rows * pitch per colour channel
 
 __global__ void __launch_bounds__(kBlock)
 k_resolve(FrameMap fm, SlotBase first, int nPixels, int ppb, Pool P, unsigned char* rgb, int* hitId,
