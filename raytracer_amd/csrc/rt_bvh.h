@@ -222,17 +222,16 @@ class Builder {
 
 
 // 64-byte 4-wide node with 8-bit quantised child boxes.  Child box c spans
-// origin + q * 2^exp per axis (lower planes rounded down, upper planes rounded
+// origin + q * scale per axis, scale a power of two (lower planes rounded down, upper planes rounded
 // up, so the decoded box always contains the builder's box).  child[c] uses the
 // encoding of Node::child; kEmptyChild marks an unused slot.
 struct Node4 {
   float origin[3];
-  int8_t exp[3];
-  uint8_t pad0;
+  float scaleX;      // 2^exp of the x axis, as the number the traversal multiplies by
   int32_t child[4];
   uint32_t qlo[3];   // byte c of qlo[a]: lower plane of child c on axis a
   uint32_t qhi[3];
-  uint32_t pad1[2];
+  float scaleY, scaleZ;
 };
 static_assert(sizeof(Node4) == 64, "BVH4 node must be 64 bytes");
 constexpr int32_t kEmptyChild = 0x7fffffff;
@@ -285,6 +284,7 @@ class Collapser {
       std::memset(&out, 0, sizeof out);
       Box all; all.reset();
       for (const Kid& k : kids) all.grow(k.box);
+      int exps[3];
       for (int a = 0; a < 3; a++) {
         out.origin[a] = down(all.lo[a]);
         const double ext = all.hi[a] - (double)out.origin[a];
@@ -294,8 +294,11 @@ class Collapser {
           while (std::ldexp(255.0, e) < ext) e++;   // guard the rounding of log2
           e = std::max(-126, std::min(127, e));
         }
-        out.exp[a] = (int8_t)e;
+        exps[a] = e;
       }
+      out.scaleX = (float)std::ldexp(1.0, exps[0]);
+      out.scaleY = (float)std::ldexp(1.0, exps[1]);
+      out.scaleZ = (float)std::ldexp(1.0, exps[2]);
       for (int c = 0; c < 4; c++) {
         if (c >= (int)kids.size()) {
           out.child[c] = kEmptyChild;
@@ -304,7 +307,7 @@ class Collapser {
         }
         const Kid& k = kids[c];
         for (int a = 0; a < 3; a++) {
-          const double sc = std::ldexp(1.0, out.exp[a]);
+          const double sc = std::ldexp(1.0, exps[a]);
           double ql = std::floor((k.box.lo[a] - (double)out.origin[a]) / sc);
           double qh = std::ceil((k.box.hi[a] - (double)out.origin[a]) / sc);
           ql = std::min(255.0, std::max(0.0, ql));

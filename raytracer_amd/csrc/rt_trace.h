@@ -60,12 +60,11 @@ struct DevTriFast {
 // Byte c of qlo[a] / qhi[a] is the lower / upper plane of child c on axis a.
 struct DevBvhNode {
   float origin[3];
-  int8_t exp[3];
-  uint8_t pad0;
+  float scaleX;       // plane q of axis a lies at origin[a] + q * scale (a power of two)
   int child[4];
   uint32_t qlo[3];
   uint32_t qhi[3];
-  uint32_t pad1[2];
+  float scaleY, scaleZ;
 };
 #define RT_BVH_OBJECT_BIT 0x40000000
 #define RT_BVH_EMPTY 0x7fffffff
@@ -598,12 +597,6 @@ __device__ __forceinline__ float roundUpF(double x) {
   return fmaf(fabsf(f), 0x1p-23f, f) + 1.0e-37f;
 }
 
-// 2^e, e in [-126, 127]
-__device__ __forceinline__ double pow2i(int e) {
-  return __longlong_as_double((long long)(e + 1023) << 52);
-}
-__device__ __forceinline__ float pow2f(int e) { return __int_as_float((e + 127) << 23); }
-
 typedef float rt_f2 __attribute__((ext_vector_type(2)));
 
 // Slab distances of two children at once: q * B + A on both lanes of a packed
@@ -688,18 +681,17 @@ __device__ __forceinline__ void bvhNodeSlabs(const DevScene& S, const V3& p, con
   const float kInf = __int_as_float(0x7f800000);
   const uint4* np = reinterpret_cast<const uint4*>(S.bvh + ref);
   const uint4 w0 = np[0], w1 = np[1], w2 = np[2];
-  const uint2 w3 = *reinterpret_cast<const uint2*>(np + 3);
+  const uint4 w3 = np[3];
   const float ox = __uint_as_float(w0.x), oy = __uint_as_float(w0.y), oz = __uint_as_float(w0.z);
-  const int ex = (int)(int8_t)(w0.w & 255u), ey = (int)(int8_t)((w0.w >> 8) & 255u),
-            ez = (int)(int8_t)((w0.w >> 16) & 255u);
+  const float sx = __uint_as_float(w0.w), sy = __uint_as_float(w3.z), sz = __uint_as_float(w3.w);
   kid[0] = (int)w1.x; kid[1] = (int)w1.y; kid[2] = (int)w1.z; kid[3] = (int)w1.w;
-  // A = (origin - p) / d, B = 2^exp / d: plane q lies at distance A + q * B.
+  // A = (origin - p) / d, B = scale / d: plane q lies at distance A + q * B.
   // All in binary32: A = origin * inv - p * inv (the second product once per ray);
   // the roundings of both products, of their difference, of B and of the fused
   // multiply-add stay below 2^-22 (|origin inv| + |p inv| + 255 |B|), half of
   // what the planes are widened by.  (Far from the world origin the widening
   // grows relative to the boxes: culling gets weaker, never wrong.)
-  float bx = r.ivx * pow2f(ex), by = r.ivy * pow2f(ey), bz = r.ivz * pow2f(ez);
+  float bx = r.ivx * sx, by = r.ivy * sy, bz = r.ivz * sz;
   const float oix = ox * r.ivx, oiy = oy * r.ivy, oiz = oz * r.ivz;
   const float afx = oix - r.pix, afy = oiy - r.piy, afz = oiz - r.piz;
   const float errx = fmaf(0x1p-21f, fmaf(255.0f, fabsf(bx), fabsf(oix)), r.epx);
@@ -715,17 +707,17 @@ __device__ __forceinline__ void bvhNodeSlabs(const DevScene& S, const V3& p, con
     // the entry at +huge or the exit at -huge when it does not.
     const float K = 0x1p40f;
     if (r.zx) {
-      const float u = fminf(fmaxf((float)((p.x - (double)ox) * pow2i(-ex)), -1.0e9f), 1.0e9f);
+      const float u = fminf(fmaxf((float)((p.x - (double)ox) / (double)sx), -1.0e9f), 1.0e9f);
       const float m = fmaf(fabsf(u), 0x1p-21f, 0x1p-20f);
       bx = K; a0x = -K * (u + m); a1x = -K * (u - m);
     }
     if (r.zy) {
-      const float u = fminf(fmaxf((float)((p.y - (double)oy) * pow2i(-ey)), -1.0e9f), 1.0e9f);
+      const float u = fminf(fmaxf((float)((p.y - (double)oy) / (double)sy), -1.0e9f), 1.0e9f);
       const float m = fmaf(fabsf(u), 0x1p-21f, 0x1p-20f);
       by = K; a0y = -K * (u + m); a1y = -K * (u - m);
     }
     if (r.zz) {
-      const float u = fminf(fmaxf((float)((p.z - (double)oz) * pow2i(-ez)), -1.0e9f), 1.0e9f);
+      const float u = fminf(fmaxf((float)((p.z - (double)oz) / (double)sz), -1.0e9f), 1.0e9f);
       const float m = fmaf(fabsf(u), 0x1p-21f, 0x1p-20f);
       bz = K; a0z = -K * (u + m); a1z = -K * (u - m);
     }
