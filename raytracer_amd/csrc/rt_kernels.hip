@@ -258,11 +258,17 @@ __device__ __forceinline__ void flushCounters(const TraceCounters& c, Counters* 
   }
 }
 
-#ifdef RT_TRACE_WAVES
-#define RT_TRACE_ATTR __attribute__((amdgpu_waves_per_eu(RT_TRACE_WAVES, RT_TRACE_WAVES)))
-#else
-#define RT_TRACE_ATTR
+// Resident wavefronts per SIMD the triangle-only BVH traversal kernels are
+// compiled for.  Five is what the closest-hit kernel gets by itself (87
+// registers); the shadow kernel lands one register past that step (97) and
+// gains 12 % from being held to it.  (Six: both kernels spill and lose more
+// than the extra wavefront hides.)  The BVH kernels with every primitive kind
+// are held to four (125-129 registers by themselves, on either side of that
+// step); the reference's KD traversal keeps what the compiler gives it.
+#ifndef RT_TRACE_WAVES
+#define RT_TRACE_WAVES 5
 #endif
+#define RT_TRACE_BOUNDS(FAST, TRI) __launch_bounds__(kTraceBlock, (FAST) ? ((TRI) ? RT_TRACE_WAVES : 4) : 1)
 
 // Closest hit of every ray of a level, one ray per thread.  (A streaming form in
 // which a wavefront refills finished lanes from a run of rays was measured 1.6x
@@ -287,8 +293,12 @@ __device__ __forceinline__ long long xcdBlock() {
   return (long long)g * span + (r & 7u) * C + (r >> 3);
 }
 
+// Dynamic LDS of the kernels that walk the BVH: the per-lane traversal stacks
+// (RT_LDS_STACK_BYTES_* per thread, set at launch).
+extern __shared__ __align__(16) uint32_t rtStackLds[];
+
 template <bool FAST, bool STATS, bool TRI>
-__global__ void __launch_bounds__(kTraceBlock) RT_TRACE_ATTR
+__global__ void RT_TRACE_BOUNDS(FAST, TRI)
 k_trace(DevScene S, int n, RaySrc R, double* hitT, int* hitPrim, Counters* counters) {
   const int i = (int)(xcdBlock() * blockDim.x + threadIdx.x);
   TraceCounters tc{0, 0};
@@ -298,7 +308,7 @@ k_trace(DevScene S, int n, RaySrc R, double* hitT, int* hitPrim, Counters* count
     int prim = RT_PRIM_NONE;
     double t = 0.0;
     if (type >= 0) {
-      if (FAST) prim = traceBvh<false, STATS, TRI>(S, p, d, type, 1.0e308, -1.0, t, tc);
+      if (FAST) prim = traceBvh<false, STATS, TRI>(S, p, d, type, 1.0e308, -1.0, t, tc, (rt_lds_u32*)rtStackLds);
       else prim = traceKdReference<STATS>(S, p, d, type, t, tc);
     }
     hitT[i] = t;
@@ -495,7 +505,7 @@ __device__ __forceinline__ void shadowQuery(const DevScene& S, const RtLight& l,
   if (l.type == RT_LIGHT_DIRECTIONAL) {
     const V3 sd = normalized(-V3(l.orientation));
     // any hit blacks a directional light out (light.cpp:21-24)
-    if (FAST) prim = traceBvh<true, STATS, TRI>(S, Q, sd, RT_RAY_SHADOW, 1.0e308, -1.0, th, tc);
+    if (FAST) prim = traceBvh<true, STATS, TRI>(S, Q, sd, RT_RAY_SHADOW, 1.0e308, -1.0, th, tc, (rt_lds_u32*)rtStackLds);
     else prim = traceKdReference<STATS>(S, Q, sd, RT_RAY_SHADOW, th, tc);
     return;
   }
@@ -508,10 +518,11 @@ __device__ __forceinline__ void shadowQuery(const DevScene& S, const RtLight& l,
   if (FAST && S.opaque) {
     // Every material has kt == 0, so the filter colour of ANY occluder in
     // front of the light is the closest occluder's: stop at the first one.
-    anyOccluder = traceBvh<true, STATS, TRI>(S, Q, sd, RT_RAY_SHADOW, limit, lightDistance, th, tc) != RT_PRIM_NONE;
+    anyOccluder = traceBvh<true, STATS, TRI>(S, Q, sd, RT_RAY_SHADOW, limit, lightDistance, th, tc,
+                                             (rt_lds_u32*)rtStackLds) != RT_PRIM_NONE;
     prim = RT_PRIM_NONE;
   } else if (FAST) {
-    prim = traceBvh<false, STATS, TRI>(S, Q, sd, RT_RAY_SHADOW, limit, -1.0, th, tc);
+    prim = traceBvh<false, STATS, TRI>(S, Q, sd, RT_RAY_SHADOW, limit, -1.0, th, tc, (rt_lds_u32*)rtStackLds);
   } else {
     prim = traceKdReference<STATS>(S, Q, sd, RT_RAY_SHADOW, th, tc);
   }
@@ -580,7 +591,7 @@ __device__ __forceinline__ V3 lightIntensityFrom(const DevScene& S, const RtLigh
 // acos, whose double-precision library code would nearly double it and halve
 // the wavefronts that hide the traversal's memory latency).
 template <bool FAST, bool STATS, bool TRI>
-__global__ void __launch_bounds__(kTraceBlock) RT_TRACE_ATTR
+__global__ void RT_TRACE_BOUNDS(FAST, TRI)
 k_shadow(DevScene S, int nMax, size_t spOff, Pool P) {
   // grid: x over the shade points of the level (at most nMax), y = light
   const long long sIdx = xcdBlock() * blockDim.x + threadIdx.x;
@@ -594,7 +605,19 @@ k_shadow(DevScene S, int nMax, size_t spOff, Pool P) {
       int prim;
       double th;
       bool anyOccluder;
-      shadowQuery<FAST, STATS, TRI>(S, S.lights[li], Q, prim, th, anyOccluder, tc);
+      const RtLight& l = S.lights[li];
+      shadowQuery<FAST, STATS, TRI>(S, l, Q, prim, th, anyOccluder, tc);
+      if (!P.shT && !anyOccluder && prim != RT_PRIM_NONE && l.type != RT_LIGHT_DIRECTIONAL) {
+        // The pool of an opaque scene keeps no hit parameter, so the closest
+        // occluder is held against the light here, with the expressions of
+        // Point/SpotLight::shadowAttenuation (light.cpp:74-80,120-126): it
+        // counts only when it lies in front of the light.
+        const V3 position(l.position);
+        const V3 sd = normalized(position - Q);
+        const V3 Qh = Q + (th * sd);
+        anyOccluder = length2(Qh - Q) < length2(position - Q);
+        prim = RT_PRIM_NONE;
+      }
       const size_t o = (size_t)li * P.cap + s;
       P.shPrim[o] = anyOccluder ? RT_PRIM_ANY : prim;
       if (P.shT) P.shT[o] = th;
@@ -879,7 +902,7 @@ k_intersect(DevScene S, int n, const double* rays, const int* types, RtHit* hits
   const int type = types ? types[i] : RT_RAY_VISIBILITY;
   TraceCounters tc{0, 0};
   double t;
-  const int prim = FAST ? traceBvh<false, false>(S, p, d, type, 1.0e308, -1.0, t, tc)
+  const int prim = FAST ? traceBvh<false, false>(S, p, d, type, 1.0e308, -1.0, t, tc, (rt_lds_u32*)rtStackLds)
                         : traceKdReference<false>(S, p, d, type, t, tc);
   RtHit h;
   h.t = 1000.0;                      // scene.cpp:155
@@ -1212,18 +1235,22 @@ struct RenderCtx {
 template <bool FAST, bool STATS>
 void launchTrace(RtScene* sc, const Pool& P, int n, const RaySrc& R) {
   const int blocks = (int)(((long long)n + kTraceBlock - 1) / kTraceBlock);
+  const size_t lds = FAST ? (size_t)RT_LDS_STACK_BYTES_CLOSEST * kTraceBlock : 0;
   if (FAST && sc->triOnly)
-    k_trace<FAST, STATS, true><<<blocks, kTraceBlock, 0, sc->stream>>>(sc->dev, n, R, P.hitT, P.hitPrim, P.counters);
+    k_trace<FAST, STATS, true><<<blocks, kTraceBlock, lds, sc->stream>>>(sc->dev, n, R, P.hitT, P.hitPrim, P.counters);
   else
-    k_trace<FAST, STATS, false><<<blocks, kTraceBlock, 0, sc->stream>>>(sc->dev, n, R, P.hitT, P.hitPrim, P.counters);
+    k_trace<FAST, STATS, false><<<blocks, kTraceBlock, lds, sc->stream>>>(sc->dev, n, R, P.hitT, P.hitPrim, P.counters);
 }
 template <bool FAST, bool STATS>
 void launchShadow(RtScene* sc, hipStream_t st, const Pool& P, int nMax, size_t spOff) {
   const dim3 grid((unsigned int)(((long long)nMax + kTraceBlock - 1) / kTraceBlock), (unsigned int)sc->dev.n_lights);
+  // opaque scenes: occlusion queries (4-byte stack entries) except for directional
+  // lights, which use them anyway; otherwise closest-hit queries bounded by the light
+  const size_t lds = !FAST ? 0 : (size_t)(sc->dev.opaque ? RT_LDS_STACK_BYTES_ANYHIT : RT_LDS_STACK_BYTES_CLOSEST) * kTraceBlock;
   if (FAST && sc->triOnly)
-    k_shadow<FAST, STATS, true><<<grid, kTraceBlock, 0, st>>>(sc->dev, nMax, spOff, P);
+    k_shadow<FAST, STATS, true><<<grid, kTraceBlock, lds, st>>>(sc->dev, nMax, spOff, P);
   else
-    k_shadow<FAST, STATS, false><<<grid, kTraceBlock, 0, st>>>(sc->dev, nMax, spOff, P);
+    k_shadow<FAST, STATS, false><<<grid, kTraceBlock, lds, st>>>(sc->dev, nMax, spOff, P);
 }
 
 bool timedBegin(RtScene* sc, hipStream_t st) {
@@ -1730,9 +1757,43 @@ int rt_scene_create(const RtSceneDesc* d, RtScene** out) {
       HIP_TRY(upload(reinterpret_cast<const DevBvhNode*>(wide.nodes.data()), wide.nodes.size(), &bn));
       keep(bn);
       D.bvh = bn;
+      {
+        // the same child boxes decoded to binary32 planes, outward rounded
+        static_assert(sizeof(DevBvhNodeF) == 128, "float BVH node must be 128 bytes");
+        std::vector<DevBvhNodeF> fn(wide.nodes.size());
+        for (size_t i = 0; i < fn.size(); i++) {
+          const rtbvh::Node4& n4 = wide.nodes[i];
+          DevBvhNodeF& F = fn[i];
+          std::memset(&F, 0, sizeof F);
+          float* lo[3] = {F.lo_x, F.lo_y, F.lo_z};
+          float* hi[3] = {F.hi_x, F.hi_y, F.hi_z};
+          const double sc[3] = {n4.scaleX, n4.scaleY, n4.scaleZ};
+          for (int c = 0; c < 4; c++) {
+            F.child[c] = n4.child[c];
+            for (int a = 0; a < 3; a++) {
+              const double ql = (double)((n4.qlo[a] >> (8 * c)) & 255u), qh = (double)((n4.qhi[a] >> (8 * c)) & 255u);
+              lo[a][c] = rtbvh::down((double)n4.origin[a] + ql * sc[a]);
+              hi[a][c] = rtbvh::up((double)n4.origin[a] + qh * sc[a]);
+            }
+          }
+        }
+        DevBvhNodeF* fp;
+        HIP_TRY(upload(fn.data(), fn.size(), &fp));
+        keep(fp);
+        D.bvhF = fp;
+      }
       for (int a = 0; a < 3; a++) {
         D.bvh_bb_min[a] = bvh.rootBox.lo[a];
         D.bvh_bb_max[a] = bvh.rootBox.hi[a];
+      }
+      // 255 * scale + |origin| of every node, bounded from the nodes themselves
+      {
+        double g[3] = {0.0, 0.0, 0.0};
+        for (const rtbvh::Node4& n4 : wide.nodes) {
+          const double sc[3] = {n4.scaleX, n4.scaleY, n4.scaleZ};
+          for (int a = 0; a < 3; a++) g[a] = std::max(g[a], 255.0 * sc[a] + std::fabs((double)n4.origin[a]));
+        }
+        for (int a = 0; a < 3; a++) D.bvhErrG[a] = rtbvh::up(g[a] * (1.0 + 1e-6));
       }
     }
   }
@@ -2089,7 +2150,8 @@ int rt_intersect_batch(RtScene* sc, int traversal, int n, const double* rays_pd,
   if (ray_types) HIP_TRY(types.allocCopy(ray_types, (size_t)n * sizeof(int)));
   HIP_TRY(hitBuf.alloc((size_t)n * sizeof(RtHit)));
   if (traversal == RT_TRAVERSE_FAST)
-    k_intersect<true><<<gridFor(n), kBlock, 0, sc->stream>>>(sc->dev, n, rays.as<double>(), types.as<int>(), hitBuf.as<RtHit>());
+    k_intersect<true><<<gridFor(n), kBlock, (size_t)RT_LDS_STACK_BYTES_CLOSEST * kBlock, sc->stream>>>(
+        sc->dev, n, rays.as<double>(), types.as<int>(), hitBuf.as<RtHit>());
   else
     k_intersect<false><<<gridFor(n), kBlock, 0, sc->stream>>>(sc->dev, n, rays.as<double>(), types.as<int>(), hitBuf.as<RtHit>());
   HIP_TRY(hipGetLastError());

@@ -69,6 +69,17 @@ struct DevBvhNode {
 #define RT_BVH_OBJECT_BIT 0x40000000
 #define RT_BVH_EMPTY 0x7fffffff
 
+// The same node with its child boxes as plain binary32 world-space planes
+// (lower planes rounded down, upper planes up), 128 bytes, axis by axis:
+// lo[a][c] / hi[a][c] = lower / upper plane of child c on axis a.  This copy is
+// read through the scalar cache when every lane of a wavefront is at the same
+// node (bvhNodeSlabsUniform); DevBvhNode serves the lanes that are not.
+struct DevBvhNodeF {
+  float lo_x[4], hi_x[4], lo_y[4], hi_y[4], lo_z[4], hi_z[4];
+  int child[4];
+  int pad[4];
+};
+
 // What the shading kernels need of one (non-interpolated) material, derived
 // once at scene creation with the reference's own expressions.
 struct DevMat {
@@ -119,9 +130,13 @@ struct DevScene {
   int n_objects, n_lights, scene_root, use_kd, cull, smooth;
   // library-built BVH (RT_TRAVERSE_FAST)
   const DevBvhNode* bvh;
+  const DevBvhNodeF* bvhF;   // the same nodes, binary32 planes (wavefront-uniform visits)
   const DevTri* bvhTris;     // triangles in leaf order
   const struct DevTriFast* bvhTrisFast;   // the same triangles, what the hit decision needs only
   double bvh_bb_min[3], bvh_bb_max[3];
+  // per axis, an upper bound of 255 * scale + |origin| over every node of the BVH
+  // (what a slab distance's rounding error grows with, see bvhRaySetup)
+  float bvhErrG[3];
   int bvh_valid;             // 0: empty scene
   int opaque;                // 1: no material transmits (kt == 0 everywhere)
 };
@@ -585,7 +600,24 @@ __device__ int traceKdReference(const DevScene& S, const V3& p, const V3& d, int
 // -------------------------------------------------------------- BVH traversal
 #define RT_BVH_STACK 96
 
-struct BvhEntry { int ref; float tn; };
+// Where a lane keeps the subtrees it still has to visit.  The first
+// RT_LDS_STACK entries of every lane live in the workgroup's LDS, laid out so
+// that entry k of the workgroup's thread t sits at word (k * blockDim.x + t)
+// (times two for 8-byte entries): whatever depth each lane is at, the lanes of
+// a wavefront touch 64 different banks.  Only deeper entries go to a per-lane
+// array in scratch memory, which most rays never reach.  (With the whole stack
+// in scratch, two thirds of the bytes the closest-hit kernel wrote to HBM were
+// stack entries leaving the caches.)
+#ifndef RT_LDS_STACK
+#define RT_LDS_STACK 8
+#endif
+typedef __attribute__((address_space(3))) uint32_t rt_lds_u32;
+typedef __attribute__((address_space(3))) unsigned long long rt_lds_u64;
+
+// Bytes of dynamic LDS a traversal kernel needs per thread: closest-hit entries
+// are 8 bytes (subtree, entry distance), occlusion entries 4 (subtree).
+#define RT_LDS_STACK_BYTES_CLOSEST (RT_LDS_STACK * 8)
+#define RT_LDS_STACK_BYTES_ANYHIT (RT_LDS_STACK * 4)
 
 __device__ __forceinline__ float roundDownF(double x) {
   float f = (float)x;
@@ -617,8 +649,10 @@ struct BvhRay {
   V3 ldI;                 // object-space direction of every identity-transform mesh
   double lenI;            // (Geometry::intersect, scene.cpp:17-20: ((p+d)-p) renormalised)
   float ivx, ivy, ivz;    // inv rounded to binary32
-  float pix, piy, piz;    // p * inv rounded to binary32
-  float epx, epy, epz;    // 2^-21 |p * inv|: the origin's share of a plane distance's rounding error
+  // -(p * inv) in binary32, moved down (a0*) and up (a1*) by a bound of the
+  // rounding error of a plane distance on that axis: what entry and exit plane
+  // distances are offset by
+  float a0x, a1x, a0y, a1y, a0z, a1z;
   bool negx, negy, negz;  // direction sign per axis (false on a degenerate axis)
   bool zx, zy, zz;        // |d| < 1e-30 on that axis: inside / outside test instead of a slab
   bool cullBack;
@@ -631,8 +665,24 @@ __device__ __forceinline__ void bvhRaySetup(const DevScene& S, const V3& p, cons
   r.zy = !(fabs(d.y) >= 1.0e-30);
   r.zz = !(fabs(d.z) >= 1.0e-30);
   r.ivx = (float)r.inv.x; r.ivy = (float)r.inv.y; r.ivz = (float)r.inv.z;
-  r.pix = (float)(p.x * r.inv.x); r.piy = (float)(p.y * r.inv.y); r.piz = (float)(p.z * r.inv.z);
-  r.epx = 0x1p-21f * fabsf(r.pix); r.epy = 0x1p-21f * fabsf(r.piy); r.epz = 0x1p-21f * fabsf(r.piz);
+  // A plane at coordinate c lies at distance c * inv - p * inv.  In binary32,
+  // with c either a float (bvhNodeSlabsUniform) or origin + q * scale evaluated
+  // as q * (scale * inv) + origin * inv (bvhNodeSlabs), the roundings of the
+  // products, of their sum and of the fused multiply-add stay below
+  // 2^-22 (G |inv| + |p inv|), where G = bvhErrG bounds 255 * scale + |origin|,
+  // and so every |c|, over all nodes.  Entry distances are moved down and exit
+  // distances up by twice that: they stay lower and upper bounds.  (Far from
+  // the world origin the widening grows relative to the boxes: culling gets
+  // weaker, never wrong.)
+  {
+    const float pix = (float)(p.x * r.inv.x), piy = (float)(p.y * r.inv.y), piz = (float)(p.z * r.inv.z);
+    const float ex = 0x1p-21f * fmaf(S.bvhErrG[0], fabsf(r.ivx), fabsf(pix)) + 1.0e-37f;
+    const float ey = 0x1p-21f * fmaf(S.bvhErrG[1], fabsf(r.ivy), fabsf(piy)) + 1.0e-37f;
+    const float ez = 0x1p-21f * fmaf(S.bvhErrG[2], fabsf(r.ivz), fabsf(piz)) + 1.0e-37f;
+    r.a0x = -pix - ex; r.a1x = -pix + ex;
+    r.a0y = -piy - ey; r.a1y = -piy + ey;
+    r.a0z = -piz - ez; r.a1z = -piz + ez;
+  }
   r.negx = (d.x < 0.0) & !r.zx;
   r.negy = (d.y < 0.0) & !r.zy;
   r.negz = (d.z < 0.0) & !r.zz;
@@ -685,21 +735,12 @@ __device__ __forceinline__ void bvhNodeSlabs(const DevScene& S, const V3& p, con
   const float ox = __uint_as_float(w0.x), oy = __uint_as_float(w0.y), oz = __uint_as_float(w0.z);
   const float sx = __uint_as_float(w0.w), sy = __uint_as_float(w3.z), sz = __uint_as_float(w3.w);
   kid[0] = (int)w1.x; kid[1] = (int)w1.y; kid[2] = (int)w1.z; kid[3] = (int)w1.w;
-  // A = (origin - p) / d, B = scale / d: plane q lies at distance A + q * B.
-  // All in binary32: A = origin * inv - p * inv (the second product once per ray);
-  // the roundings of both products, of their difference, of B and of the fused
-  // multiply-add stay below 2^-22 (|origin inv| + |p inv| + 255 |B|), half of
-  // what the planes are widened by.  (Far from the world origin the widening
-  // grows relative to the boxes: culling gets weaker, never wrong.)
+  // B = scale / d: plane q lies at distance q * B + origin * inv - p * inv; the
+  // last term comes widened from the ray's setup.
   float bx = r.ivx * sx, by = r.ivy * sy, bz = r.ivz * sz;
-  const float oix = ox * r.ivx, oiy = oy * r.ivy, oiz = oz * r.ivz;
-  const float afx = oix - r.pix, afy = oiy - r.piy, afz = oiz - r.piz;
-  const float errx = fmaf(0x1p-21f, fmaf(255.0f, fabsf(bx), fabsf(oix)), r.epx);
-  const float erry = fmaf(0x1p-21f, fmaf(255.0f, fabsf(by), fabsf(oiy)), r.epy);
-  const float errz = fmaf(0x1p-21f, fmaf(255.0f, fabsf(bz), fabsf(oiz)), r.epz);
-  float a0x = afx - errx, a1x = afx + errx;
-  float a0y = afy - erry, a1y = afy + erry;
-  float a0z = afz - errz, a1z = afz + errz;
+  float a0x = fmaf(ox, r.ivx, r.a0x), a1x = fmaf(ox, r.ivx, r.a1x);
+  float a0y = fmaf(oy, r.ivy, r.a0y), a1y = fmaf(oy, r.ivy, r.a1y);
+  float a0z = fmaf(oz, r.ivz, r.a0z), a1z = fmaf(oz, r.ivz, r.a1z);
   if (r.zx | r.zy | r.zz) {
     // The ray runs parallel to the slabs of this axis: with u = the origin in
     // grid units, K (q_lo - u) and K (q_hi - u) for a huge K put the entry at
@@ -736,6 +777,70 @@ __device__ __forceinline__ void bvhNodeSlabs(const DevScene& S, const V3& p, con
     const float tfar1 = fminf(fminf(fminf(fx.y, fy.y), fz.y), bestTf);
     // (an unused slot has an inverted box; should rounding ever let one pass,
     // it leads to a leaf of one null triangle)
+    const bool h0 = (tnear0 <= tfar0) & (tfar0 >= 0.0f);
+    const bool h1 = (tnear1 <= tfar1) & (tfar1 >= 0.0f);
+    tn[c] = h0 ? tnear0 : kInf;
+    tn[c + 1] = h1 ? tnear1 : kInf;
+  }
+}
+
+typedef float rt_f4 __attribute__((ext_vector_type(4)));
+typedef int rt_i4 __attribute__((ext_vector_type(4)));
+
+// bvhNodeSlabs for a node that every active lane of the wavefront is visiting
+// (`ref` is wavefront-uniform) by rays that share their direction signs
+// (`negMask`: bit a set = direction negative on axis a, wavefront-uniform) and
+// have no axis-parallel component.  The node comes through the scalar cache
+// into scalar registers -- no vector-memory instruction, no byte-to-float
+// conversion -- and each plane distance is one multiply-add plane * inv - p *
+// inv, widened by the ray's error bound: |plane| <= bvhErrG, so the bound of
+// bvhRaySetup covers the roundings of this form as well.
+__device__ __forceinline__ void bvhNodeSlabsUniform(const DevScene& S, const BvhRay& r, int ref, unsigned int negMask,
+                                                    float bestTf, float tn[4], int kid[4]) {
+  const float kInf = __int_as_float(0x7f800000);
+  const char* np = reinterpret_cast<const char*>(S.bvhF + ref);
+  // entry planes of an axis: the lower ones unless the rays run down that axis
+  const unsigned int oNX = (negMask & 1u) ? 16u : 0u, oNY = (negMask & 2u) ? 48u : 32u, oNZ = (negMask & 4u) ? 80u : 64u;
+  const unsigned int oFX = oNX ^ 16u, oFY = oNY ^ 16u, oFZ = oNZ ^ 16u;
+  rt_f4 nX, fX, nY, fY, nZ, fZ;
+  rt_i4 kids;
+  asm volatile(
+      "s_load_dwordx4 %0, %7, %8\n\t"
+      "s_load_dwordx4 %1, %7, %9\n\t"
+      "s_load_dwordx4 %2, %7, %10\n\t"
+      "s_load_dwordx4 %3, %7, %11\n\t"
+      "s_load_dwordx4 %4, %7, %12\n\t"
+      "s_load_dwordx4 %5, %7, %13\n\t"
+      "s_load_dwordx4 %6, %7, 0x60\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&s"(nX), "=&s"(fX), "=&s"(nY), "=&s"(fY), "=&s"(nZ), "=&s"(fZ), "=&s"(kids)
+      : "s"(np), "s"(oNX), "s"(oFX), "s"(oNY), "s"(oFY), "s"(oNZ), "s"(oFZ)
+      : "memory");
+  kid[0] = kids.x; kid[1] = kids.y; kid[2] = kids.z; kid[3] = kids.w;
+  // Two children per packed multiply-add: planes from a scalar register pair,
+  // the reciprocal and the offset picked out of register pairs of the ray's
+  // state by the instruction's operand selects (written out by hand: left to
+  // itself the compiler copies every selected value into a pair of its own,
+  // eighteen registers more per lane).
+  const rt_f2 ivXY = {r.ivx, r.ivy}, ivZZ = {r.ivz, r.ivz};
+  const rt_f2 aX = {r.a0x, r.a1x}, aY = {r.a0y, r.a1y}, aZ = {r.a0z, r.a1z};
+#define RT_PKFMA(dst, planes, ivp, ap, sel)                                                     \
+  asm("v_pk_fma_f32 %0, %1, %2, %3 " sel : "=v"(dst) : "s"(planes), "v"(ivp), "v"(ap))
+#pragma unroll
+  for (int c = 0; c < 4; c += 2) {
+    const rt_f2 pnx = {nX[c], nX[c + 1]}, pfx = {fX[c], fX[c + 1]};
+    const rt_f2 pny = {nY[c], nY[c + 1]}, pfy = {fY[c], fY[c + 1]};
+    const rt_f2 pnz = {nZ[c], nZ[c + 1]}, pfz = {fZ[c], fZ[c + 1]};
+    rt_f2 nx, fx, ny, fy, nz, fz;
+    RT_PKFMA(nx, pnx, ivXY, aX, "op_sel_hi:[1,0,0]");                   // planes * ivx + a0x
+    RT_PKFMA(fx, pfx, ivXY, aX, "op_sel:[0,0,1] op_sel_hi:[1,0,1]");    // planes * ivx + a1x
+    RT_PKFMA(ny, pny, ivXY, aY, "op_sel:[0,1,0] op_sel_hi:[1,1,0]");    // planes * ivy + a0y
+    RT_PKFMA(fy, pfy, ivXY, aY, "op_sel:[0,1,1] op_sel_hi:[1,1,1]");    // planes * ivy + a1y
+    RT_PKFMA(nz, pnz, ivZZ, aZ, "op_sel_hi:[1,0,0]");                   // planes * ivz + a0z
+    RT_PKFMA(fz, pfz, ivZZ, aZ, "op_sel:[0,0,1] op_sel_hi:[1,0,1]");    // planes * ivz + a1z
+    const float tnear0 = fmaxf(fmaxf(nx.x, ny.x), nz.x), tnear1 = fmaxf(fmaxf(nx.y, ny.y), nz.y);
+    const float tfar0 = fminf(fminf(fminf(fx.x, fy.x), fz.x), bestTf);
+    const float tfar1 = fminf(fminf(fminf(fx.y, fy.y), fz.y), bestTf);
     const bool h0 = (tnear0 <= tfar0) & (tfar0 >= 0.0f);
     const bool h1 = (tnear1 <= tfar1) & (tfar1 >= 0.0f);
     tn[c] = h0 ? tnear0 : kInf;
@@ -787,7 +892,7 @@ __device__ __forceinline__ bool bvhLeaf(const DevScene& S, const V3& p, const V3
     const int first = x >> 3, count = (x & 7) + 1;
     for (int k = 0; k < count; k++) {
 #ifdef RT_DIVERGENCE_STATS
-      if (STATS && (threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) cnt.prims++;
+      if (STATS && RT_DIVERGENCE_STATS != 3 && (threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) cnt.prims++;
 #else
       if (STATS) cnt.prims++;
 #endif
@@ -839,7 +944,7 @@ __device__ __forceinline__ bool bvhLeaf(const DevScene& S, const V3& p, const V3
 // RT_PRIM_NONE.
 template <bool ANYHIT, bool STATS, bool TRI = false>
 __device__ int traceBvh(const DevScene& S, const V3& p, const V3& d, int rayType, double tLimit,
-                        double occDist2, double& tOut, TraceCounters& cnt) {
+                        double occDist2, double& tOut, TraceCounters& cnt, rt_lds_u32* ldsStack) {
   tOut = 0.0;
   if (!S.bvh_valid) return RT_PRIM_NONE;
   if (anynan(d) || anynan(p)) {
@@ -880,35 +985,92 @@ __device__ int traceBvh(const DevScene& S, const V3& p, const V3& d, int rayType
   double bestT = tLimit;   // doubles as the far cull bound until a hit exists
   float bestTf = roundUpF(bestT);
   int bestPrim = RT_PRIM_NONE;
-  // The newest stack entry stays in registers (topRef / topTn), the rest in
-  // scratch memory: a pop then hands out the register entry at once and the
-  // load that refills it overlaps the work on the popped subtree.
-  BvhEntry stack[RT_BVH_STACK];
+  const unsigned int ldsStride = blockDim.x;
+  rt_lds_u32* const col32 = ldsStack + threadIdx.x;
+  rt_lds_u64* const col64 = (rt_lds_u64*)ldsStack + threadIdx.x;
+  unsigned long long deep[RT_BVH_STACK - RT_LDS_STACK];   // entries past the LDS part
   int sp = 0;
+#define RT_STACK_STORE(K, R, T)                                                    \
+  {                                                                                \
+    if ((K) < RT_LDS_STACK) {                                                      \
+      if (ANYHIT) col32[(unsigned int)(K) * ldsStride] = (uint32_t)(R);            \
+      else col64[(unsigned int)(K) * ldsStride] =                                  \
+          ((unsigned long long)__float_as_uint(T) << 32) | (uint32_t)(R);          \
+    } else {                                                                       \
+      deep[(K) - RT_LDS_STACK] =                                                   \
+          ((unsigned long long)__float_as_uint(T) << 32) | (uint32_t)(R);          \
+    }                                                                              \
+  }
+#define RT_STACK_LOAD(K, R, T)                                                     \
+  {                                                                                \
+    if ((K) < RT_LDS_STACK) {                                                      \
+      if (ANYHIT) {                                                                \
+        R = (int)col32[(unsigned int)(K) * ldsStride];                             \
+      } else {                                                                     \
+        const unsigned long long e_ = col64[(unsigned int)(K) * ldsStride];        \
+        R = (int)(uint32_t)e_;                                                     \
+        T = __uint_as_float((uint32_t)(e_ >> 32));                                 \
+      }                                                                            \
+    } else {                                                                       \
+      const unsigned long long e_ = deep[(K) - RT_LDS_STACK];                      \
+      R = (int)(uint32_t)e_;                                                       \
+      T = __uint_as_float((uint32_t)(e_ >> 32));                                   \
+    }                                                                              \
+  }
+#ifdef RT_STACK_NOTOP
+  // every entry in memory (depth checked at scene creation)
+#define RT_BVH_PUSH(R, T) { RT_STACK_STORE(sp, R, T) sp++; }
+#else
+  // The newest stack entry stays in registers (topRef / topTn), the rest in
+  // LDS (see RT_LDS_STACK): a pop then hands out the register entry at once and
+  // the load that refills it overlaps the work on the popped subtree.
   int topRef = RT_BVH_EMPTY;
   float topTn = 0.0f;
 #define RT_BVH_PUSH(R, T)                                                          \
   {                                                                                \
     if (topRef != RT_BVH_EMPTY) {   /* depth checked at scene creation */          \
-      stack[sp].ref = topRef;                                                      \
-      if (!ANYHIT) stack[sp].tn = topTn;                                           \
+      RT_STACK_STORE(sp, topRef, topTn)                                            \
       sp++;                                                                        \
     }                                                                              \
     topRef = (R);                                                                  \
     topTn = (T);                                                                   \
   }
+#endif
   int ref = 0;
   const float kInf = __int_as_float(0x7f800000);
+#ifndef RT_NO_UNIFORM_PATH
+  // wavefront-wide facts about the rays that are still here: do they share their
+  // direction signs, and is none of them parallel to an axis
+  const unsigned int myNeg = (r.negx ? 1u : 0u) | (r.negy ? 2u : 0u) | (r.negz ? 4u : 0u);
+  const unsigned int negMask = (unsigned int)__builtin_amdgcn_readfirstlane((int)myNeg);
+  const bool uniformOk = __ballot((myNeg != negMask) | r.zx | r.zy | r.zz) == 0;
+#endif
   for (;;) {
     if (ref >= 0) {
 #ifdef RT_DIVERGENCE_STATS   // diagnostics build: count wavefront iterations instead of lane visits
       if (STATS && RT_DIVERGENCE_STATS != 2 && (threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) cnt.nodes++;
+#if RT_DIVERGENCE_STATS == 3   // ... and, as "primitives", those in which every lane at a node is at the same node
+      {
+        const int uref = __builtin_amdgcn_readfirstlane(ref);
+        if (STATS && __ballot(ref != uref) == 0 && (threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) cnt.prims++;
+      }
+#endif
 #else
       if (STATS) cnt.nodes++;
 #endif
       float tn[4];
       int kid[4];
-      bvhNodeSlabs(S, p, r, ref, bestTf, tn, kid);
+#ifndef RT_NO_UNIFORM_PATH
+      // Three node visits in four find every lane of the wavefront at the same
+      // node (neighbouring samples, neighbouring shade points): those take the
+      // scalar form of the slab test.  (Mesh scenes only: in the kernels that
+      // also carry the code of the other primitive kinds its 28 scalar registers
+      // push vector registers over an occupancy step.)
+      const int uref = __builtin_amdgcn_readfirstlane(ref);
+      if (TRI && uniformOk && __ballot(ref != uref) == 0) bvhNodeSlabsUniform(S, r, uref, negMask, bestTf, tn, kid);
+      else
+#endif
+        bvhNodeSlabs(S, p, r, ref, bestTf, tn, kid);
       if (ANYHIT) {
         // Every overlapped subtree has to be searched unless an occluder turns
         // up, so only the descent wants an order: nearest child next, the
@@ -945,20 +1107,31 @@ __device__ int traceBvh(const DevScene& S, const V3& p, const V3& d, int rayType
     }
     // pop the next subtree that can still contain a closer hit
     bool found = false;
+#ifdef RT_STACK_NOTOP
+    while (sp > 0) {
+      --sp;
+      int candRef;
+      float candTn = 0.0f;
+      RT_STACK_LOAD(sp, candRef, candTn)
+      if (ANYHIT || (double)candTn <= bestT) { ref = candRef; found = true; break; }
+    }
+#else
     while (topRef != RT_BVH_EMPTY) {
       const int candRef = topRef;
       const float candTn = topTn;
       if (sp > 0) {
         --sp;
-        topRef = stack[sp].ref;
-        if (!ANYHIT) topTn = stack[sp].tn;
+        RT_STACK_LOAD(sp, topRef, topTn)
       } else {
         topRef = RT_BVH_EMPTY;
       }
       if (ANYHIT || (double)candTn <= bestT) { ref = candRef; found = true; break; }
     }
+#endif
     if (!found) break;
   }
+#undef RT_STACK_STORE
+#undef RT_STACK_LOAD
 #undef RT_BVH_PUSH
   tOut = haveOne ? bestT : 0.0;
   return bestPrim;

@@ -95,3 +95,34 @@ def assert_parity(rgb, hits, ref_rgb, ref_hits, exact=True, what=""):
         # libm pow/acos may differ in the last bit between glibc and the device
         # library; that can move a byte only when 255*c sits on an integer
         assert off0 <= max(2, n // 2000), msg
+
+
+def closed_room_scene():
+    """A closed room of six opaque boxes with the camera, a point light and a spot
+    light inside it, and opaque things on the floor: every shadow ray ends on a
+    wall BEHIND its light, so an occluder only counts when it lies in front of the
+    light (light.cpp:77-80,123-126)."""
+    s = scenes.HEADER
+    s += scenes.camera((0.0713, 2.1137, -3.4213), (0.02, -0.18, 1.0), aspect=1.0, fov=55.0)
+    s += scenes.ambient_light((0.12, 0.12, 0.12))
+    s += scenes.point_light((0.6237, 3.8411, 0.2173), color=(0.9, 0.9, 0.8))
+    s += scenes.spot_light((-1.4119, 4.1273, -1.3371), (0.3, -1.0, 0.4), color=(0.7, 0.8, 1.0),
+                           atten_angle=50.0, fall_rate=3.0)
+    white = scenes.material(diffuse=(0.7, 0.7, 0.7), ambient=(0.7, 0.7, 0.7), specular=(0.2, 0.2, 0.2), shininess=12.0)
+    red = scenes.material(diffuse=(0.7, 0.15, 0.1), ambient=(0.7, 0.15, 0.1))
+    shiny = scenes.material(diffuse=(0.2, 0.3, 0.6), ambient=(0.2, 0.3, 0.6), specular=(0.7, 0.7, 0.7),
+                            shininess=60.0, reflective=(0.35, 0.35, 0.35))
+    s += scenes.translate((0.0, -0.25, 0.0), scenes.scale((9.0, 0.5, 9.0), scenes.prim("box", white)))     # floor
+    s += scenes.translate((0.0, 5.25, 0.0), scenes.scale((9.0, 0.5, 9.0), scenes.prim("box", white)))      # ceiling
+    s += scenes.translate((0.0, 2.5, 4.75), scenes.scale((9.0, 6.0, 0.5), scenes.prim("box", white)))      # back
+    s += scenes.translate((0.0, 2.5, -4.75), scenes.scale((9.0, 6.0, 0.5), scenes.prim("box", white)))     # front
+    s += scenes.translate((-4.75, 2.5, 0.0), scenes.scale((0.5, 6.0, 9.0), scenes.prim("box", red)))       # left
+    s += scenes.translate((4.75, 2.5, 0.0), scenes.scale((0.5, 6.0, 9.0), scenes.prim("box", red)))        # right
+    s += scenes.translate((-1.1123, 1.0, 1.6117), scenes.prim("sphere", shiny))
+    s += scenes.translate((1.5119, 0.6, 0.4123), scenes.rotate((0.0, 1.0, 0.0), 0.4,
+                                                                scenes.scale((1.2, 1.2, 1.2), scenes.prim("box", red))))
+    v = np.array([[-0.6013, 0.0011, -1.2], [0.7017, 0.0013, -1.1], [0.0511, 1.3017, -0.9],
+                  [0.1013, 0.0012, -0.3]])
+    f = np.array([[0, 2, 1], [1, 2, 3], [3, 2, 0]])
+    s += scenes.trimesh(v, f, white, gennormals=False)
+    return s

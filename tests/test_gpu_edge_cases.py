@@ -80,6 +80,19 @@ def test_degenerate_and_sliver_faces(built):
         assert st.rays_shadow == rs.rays_shadow
 
 
+@pytest.mark.parametrize("trav", BOTH)
+@pytest.mark.parametrize("kd", [True, False])
+def test_lights_inside_a_closed_opaque_room(built, trav, kd):
+    """No material transmits and every shadow ray hits a wall behind its light:
+    the closest occluder darkens a light only from in front of it
+    (light.cpp:77-80,123-126), with the KD-tree and with the linear scan."""
+    hs = host.HostScene(text=common.closed_room_scene(), kd_tree=kd)
+    rgb, hits, st, (rr, rh, rs) = _both(hs, width=96, height=96, depth=2, traversal=trav)
+    assert rr.reshape(-1, 3).max(axis=1).mean() > 60, "the room should be lit"
+    common.assert_parity(rgb, hits, rr, rh, what="closed room kd=%s" % kd)
+    assert st.rays_shadow == rs.rays_shadow and st.shade_points == rs.shade_points
+
+
 def test_largest_sample_grid(built):
     hs = host.HostScene(text=scenes.simple_scene())
     jit = host.jitter_table(7, 8)
