@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RT_AMD_ABI_VERSION 2
+#define RT_AMD_ABI_VERSION 3
 
 typedef enum RtError {
   RT_OK = 0,
@@ -197,6 +197,8 @@ typedef struct RtStats {
   int    lights_launches;
   int    _pad;
   unsigned long long shadow_nodes_visited, shadow_prims_tested;  /* shadow rays' share of the two totals */
+  int    batches_redone;     /* batches repeated because a recursion level outgrew the grid estimated for it */
+  int    _pad2;
 } RtStats;
 
 /* Result of Scene::intersect for one ray (isect, src/scene/ray.h:57-112). */

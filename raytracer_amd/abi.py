@@ -3,7 +3,7 @@ raytracer_amd/host/host_api.h (the host front-end).  Field order and types
 must match the headers exactly; tests/test_abi.py checks sizes and symbols."""
 import ctypes as C
 
-RT_AMD_ABI_VERSION = 2
+RT_AMD_ABI_VERSION = 3
 
 RT_RAY_VISIBILITY, RT_RAY_REFLECTION, RT_RAY_REFRACTION, RT_RAY_REFRACTIONOUT, RT_RAY_SHADOW = range(5)
 RT_LIGHT_DIRECTIONAL, RT_LIGHT_POINT, RT_LIGHT_SPOT = range(3)
@@ -81,7 +81,8 @@ class RtStats(C.Structure):
                 ("shade_points", C.c_ulonglong), ("ms_total", C.c_double), ("ms_device", C.c_double),
                 ("ms_trace", C.c_double), ("trace_launches", C.c_int), ("batches", C.c_int),
                 ("ms_lights", C.c_double), ("lights_launches", C.c_int), ("_pad", C.c_int),
-                ("shadow_nodes_visited", C.c_ulonglong), ("shadow_prims_tested", C.c_ulonglong)]
+                ("shadow_nodes_visited", C.c_ulonglong), ("shadow_prims_tested", C.c_ulonglong),
+                ("batches_redone", C.c_int), ("_pad2", C.c_int)]
 
     @property
     def rays_total(self):

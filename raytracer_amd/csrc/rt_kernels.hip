@@ -61,15 +61,23 @@ constexpr int kTraceBlock = RT_TRACE_BLOCK;   // threads per block of the traver
 struct Counters {           // device-resident, one block per recursion level
   unsigned int nsp;         // shade points appended at this level
   unsigned int nnext;       // rays appended to the next level
-  unsigned int overflow;    // pool exhausted
-  unsigned int _pad;
+  unsigned int overflow;    // RT_OVERFLOW_* seen at this level or one before it: the batch has to be redone
+  // The level's own extent, written on the device by the level before it
+  // (k_begin / k_advance): the kernels of a level read how many rays it has and
+  // where its rays and shade points start in the pool from here, so the host
+  // can queue a whole batch without waiting for any count.
+  unsigned int n;           // rays of this level
+  unsigned int rayOff;      // pool slot of its first ray
+  unsigned int spOff;       // pool index of its first shade point
+  unsigned int _pad[2];
   unsigned long long refl, refr, litsp, nodes, prims;
   unsigned long long shadowNodes, shadowPrims;   // of the shadow rays (k_lights)
 };
 
-// One counter block per recursion level, zeroed together when a batch starts
-// (levels past kCounterBlocks reuse them and zero their own).
-constexpr int kCounterBlocks = 64;
+// One counter block per recursion level (and one past the last, which the last
+// level's k_advance writes), zeroed together when a batch starts.
+constexpr int kCounterBlocks = 128;
+constexpr int kMaxDepth = kCounterBlocks - 2;
 
 struct Pool {
   size_t cap;                                    // slots
@@ -101,6 +109,17 @@ struct Pool {
 #define RT_SPM_INTERP 0x80000000u
 #define RT_SPM_LIT 0x40000000u                   // kd or ks non-zero: lights contribute
 #define RT_SPM_INDEX 0x3fffffffu
+
+// The grid of every per-level kernel is sized on the host from an ESTIMATE of
+// the level's item count (the exact count lives on the device).  A grid that
+// turns out too small leaves items undone: its first thread says so in the
+// level's counter block, the levels below are skipped (k_advance) and the host
+// redoes the batch with exact sizes.
+#define RT_OVERFLOW_POOL 1u
+#define RT_OVERFLOW_GRID 2u
+__device__ __forceinline__ void checkCoverage(Counters* c, long long covered, long long items) {
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && covered < items) c->overflow = RT_OVERFLOW_GRID;
+}
 
 // Division of a 31-bit unsigned number by a divisor that is fixed for a launch
 // (tile size, tiles per row, samples per pixel): one multiply-high and a shift
@@ -299,12 +318,14 @@ extern __shared__ __align__(16) uint32_t rtStackLds[];
 
 template <bool FAST, bool STATS, bool TRI>
 __global__ void RT_TRACE_BOUNDS(FAST, TRI)
-k_trace(DevScene S, int n, RaySrc R, double* hitT, int* hitPrim, Counters* counters) {
-  const int i = (int)(xcdBlock() * blockDim.x + threadIdx.x);
+k_trace(DevScene S, RaySrc R, double* hitT, int* hitPrim, Counters* counters) {
+  const long long n = counters->n;
+  checkCoverage(counters, (long long)gridDim.x * blockDim.x, n);
+  const long long i = xcdBlock() * blockDim.x + threadIdx.x;
   TraceCounters tc{0, 0};
   if (i < n) {
     V3 p, d;
-    const int type = rayOf(S, R, i, p, d);
+    const int type = rayOf(S, R, (int)i, p, d);
     int prim = RT_PRIM_NONE;
     double t = 0.0;
     if (type >= 0) {
@@ -315,6 +336,26 @@ k_trace(DevScene S, int n, RaySrc R, double* hitT, int* hitPrim, Counters* count
     hitPrim[i] = prim;
   }
   if (STATS) flushCounters(tc, counters, false);
+}
+
+// Sets up level 0 of a batch / hands the counts of level l on to level l+1.
+// One thread: the next level's kernels are ordered behind it on the stream.
+__global__ void k_begin(Counters* c, unsigned int n) {
+  c->n = n;
+  c->rayOff = 0;
+  c->spOff = 0;
+}
+__global__ void k_advance(Counters* c, unsigned int cap) {
+  Counters* next = c + 1;
+  const unsigned int rayOff = c->rayOff + c->n, spOff = c->spOff + c->nsp;
+  // an exhausted pool ends the batch here: nothing of the levels below is touched
+  const bool noRoom = rayOff > cap || spOff > cap || c->nnext > cap - rayOff;
+  const unsigned int flags = c->overflow | (noRoom ? RT_OVERFLOW_POOL : 0u);
+  const bool dead = flags != 0;
+  next->overflow = flags;
+  next->n = dead ? 0u : c->nnext;
+  next->rayOff = dead ? 0u : rayOff;
+  next->spOff = dead ? 0u : spOff;
 }
 
 // ---- queue compaction without a hot atomic ----------------------------------
@@ -385,31 +426,37 @@ __device__ __forceinline__ unsigned int tileSlot(const TileScan& ts, int cls, in
 // added by k_background); hits get a shade-point slot (tile compaction) and are
 // handed to the surface kernels as RT_SPM_PENDING.
 __global__ void __launch_bounds__(kBlock)
-k_classify(int n, int items, size_t rayOff, size_t spOff, int level, Pool P) {
+k_classify(int items, int level, Pool P) {
   __shared__ TileScan ts;
-  const int tileBase = blockIdx.x * kBlock * items;
-  unsigned int hitMask = 0;
-  for (int k = 0; k < items; k++) {
-    const int i = tileBase + k * kBlock + threadIdx.x;
-    const bool hit = i < n && P.hitPrim[i] != RT_PRIM_NONE;   // k_trace leaves none in an empty slot
-    hitMask |= (hit ? 1u : 0u) << k;
-    tileCount(ts, 0, k, hit);
-  }
-  unsigned int tot0 = 0, tot1 = 0;
-  tileReserve(ts, items, 1, &P.counters->nsp, tot0, tot1);
-  for (int k = 0; k < items; k++) {
-    const int i = tileBase + k * kBlock + threadIdx.x;
-    const bool isHit = (hitMask >> k) & 1u;
-    const unsigned int s = tileSlot(ts, 0, k, isHit);
-    if (i >= n) continue;
-    if (!isHit) {
-      storeV3(P.rayI, P.cap, rayOff + i, V3(0.0, 0.0, 0.0));
-      if (level == 0) P.primaryId[i] = 0;
-    } else if (spOff + s >= P.cap) {
-      P.counters->overflow = 1;
-    } else {
-      P.spRayGlobal[spOff + s] = (int)(rayOff + i);
-      P.spMat[spOff + s] = (int)RT_SPM_PENDING;
+  const long long n = P.counters->n;
+  const size_t rayOff = P.counters->rayOff, spOff = P.counters->spOff;
+  const long long perTile = (long long)kBlock * items;
+  checkCoverage(P.counters, gridDim.x * perTile, n);
+  const long long tileBase = blockIdx.x * perTile;
+  {
+    unsigned int hitMask = 0;
+    for (int k = 0; k < items; k++) {
+      const long long i = tileBase + k * kBlock + threadIdx.x;
+      const bool hit = i < n && P.hitPrim[i] != RT_PRIM_NONE;   // k_trace leaves none in an empty slot
+      hitMask |= (hit ? 1u : 0u) << k;
+      tileCount(ts, 0, k, hit);
+    }
+    unsigned int tot0 = 0, tot1 = 0;
+    tileReserve(ts, items, 1, &P.counters->nsp, tot0, tot1);
+    for (int k = 0; k < items; k++) {
+      const long long i = tileBase + k * kBlock + threadIdx.x;
+      const bool isHit = (hitMask >> k) & 1u;
+      const unsigned int s = tileSlot(ts, 0, k, isHit);
+      if (i >= n) continue;
+      if (!isHit) {
+        storeV3(P.rayI, P.cap, rayOff + i, V3(0.0, 0.0, 0.0));
+        if (level == 0) P.primaryId[i] = 0;
+      } else if (spOff + s >= P.cap) {
+        P.counters->overflow = RT_OVERFLOW_POOL;
+      } else {
+        P.spRayGlobal[spOff + s] = (int)(rayOff + i);
+        P.spMat[spOff + s] = (int)RT_SPM_PENDING;
+      }
     }
   }
 }
@@ -419,36 +466,50 @@ k_classify(int n, int items, size_t rayOff, size_t spOff, int level, Pool P) {
 // and on meshes that interpolate per-vertex materials stay pending for
 // k_surface_rest: the code of those cases more than doubles the registers of
 // this kernel, which waits on gathers and needs its wavefronts.
+// Shade points of the level that exist AND lie inside the pool: an exhausted
+// pool leaves the count above what was stored (k_classify), and every kernel
+// that walks the level's shade points stops at the pool's end.
+__device__ __forceinline__ long long shadePointsOf(const Pool& P) {
+  const long long nsp = P.counters->nsp, room = (long long)P.cap - (long long)P.counters->spOff;
+  return nsp < room ? nsp : room;
+}
+
 __global__ void __launch_bounds__(kBlock)
-k_surface(DevScene S, int nMax, RaySrc R, size_t rayOff, size_t spOff, int level, Pool P) {
-  const int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= nMax || (unsigned int)s >= P.counters->nsp || spOff + s >= P.cap) return;
-  const size_t g = spOff + s;
-  const int i = (int)((size_t)P.spRayGlobal[g] - rayOff);
-  const int prim = P.hitPrim[i];
-  if (!(prim & RT_PRIM_FACE)) return;
-  const int fi = prim & ~RT_PRIM_FACE;
-  const int info = S.faceInfo[fi];
-  if (S.smooth && (info & RT_FI_VMATERIALS)) return;
-  V3 p, d;
-  rayOf(S, R, i, p, d);
-  Surface sf;
-  surfaceNormalOfFace(S, fi, info, p, d, sf);
-  P.spMat[g] = (int)((unsigned int)(info & RT_FI_MATERIAL) | ((info & RT_FI_LIT) ? RT_SPM_LIT : 0u));   // material.cpp:50-53
-  if (level == 0) P.primaryId[i] = sf.objectID;
-  const V3 Q = p + (P.hitT[i] * d);                                    // ray::at (ray.h:42-43)
-  storeV3(P.spQ, P.cap, g, Q);
-  storeV3(P.spN, P.cap, g, sf.N);
+k_surface(DevScene S, RaySrc R, int level, Pool P) {
+  const long long nsp = shadePointsOf(P);
+  checkCoverage(P.counters, (long long)gridDim.x * blockDim.x, nsp);
+  const size_t rayOff = P.counters->rayOff, spOff = P.counters->spOff;
+  const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s < nsp) {
+    const size_t g = spOff + s;
+    const int i = (int)((size_t)P.spRayGlobal[g] - rayOff);
+    const int prim = P.hitPrim[i];
+    if (!(prim & RT_PRIM_FACE)) return;
+    const int fi = prim & ~RT_PRIM_FACE;
+    const int info = S.faceInfo[fi];
+    if (S.smooth && (info & RT_FI_VMATERIALS)) return;
+    V3 p, d;
+    rayOf(S, R, i, p, d);
+    Surface sf;
+    surfaceNormalOfFace(S, fi, info, p, d, sf);
+    P.spMat[g] = (int)((unsigned int)(info & RT_FI_MATERIAL) | ((info & RT_FI_LIT) ? RT_SPM_LIT : 0u));   // material.cpp:50-53
+    if (level == 0) P.primaryId[i] = sf.objectID;
+    const V3 Q = p + (P.hitT[i] * d);                                    // ray::at (ray.h:42-43)
+    storeV3(P.spQ, P.cap, g, Q);
+    storeV3(P.spN, P.cap, g, sf.N);
+  }
 }
 
 // The shade points k_surface left pending: hits on spheres, boxes, squares,
 // cylinders and cones, and hits whose material is interpolated from per-vertex
 // materials.  One thread per shade point of the level.
 __global__ void __launch_bounds__(kBlock)
-k_surface_rest(DevScene S, int nMax, RaySrc R, size_t rayOff, size_t spOff, int level, Pool P) {
-  const int s = blockIdx.x * blockDim.x + threadIdx.x;
-  const unsigned int nsp = P.counters->nsp;
-  if (s < nMax && (unsigned int)s < nsp && spOff + s < P.cap) {
+k_surface_rest(DevScene S, RaySrc R, int level, Pool P) {
+  const long long nsp = shadePointsOf(P);
+  checkCoverage(P.counters, (long long)gridDim.x * blockDim.x, nsp);
+  const size_t rayOff = P.counters->rayOff, spOff = P.counters->spOff;
+  const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s < nsp) {
     const size_t g = spOff + s;
     if ((unsigned int)P.spMat[g] == RT_SPM_PENDING) {
       const int i = (int)((size_t)P.spRayGlobal[g] - rayOff);
@@ -487,11 +548,14 @@ k_surface_rest(DevScene S, int nMax, RaySrc R, size_t rayOff, size_t spOff, int 
 
 // Cube-map background of the rays that hit nothing (RayTracer.cpp:213-224).
 __global__ void __launch_bounds__(kBlock)
-k_background(DevScene S, int n, RaySrc R, size_t rayOff, int filterWidth, Pool P) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+k_background(DevScene S, RaySrc R, int filterWidth, Pool P) {
+  const long long n = P.counters->n;
+  checkCoverage(P.counters, (long long)gridDim.x * blockDim.x, n);
+  const size_t rayOff = P.counters->rayOff;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n || P.hitPrim[i] != RT_PRIM_NONE) return;
   V3 p, d;
-  if (rayOf(S, R, i, p, d) >= 0) storeV3(P.rayI, P.cap, rayOff + i, cubeColor(S, d, filterWidth));
+  if (rayOf(S, R, (int)i, p, d) >= 0) storeV3(P.rayI, P.cap, rayOff + i, cubeColor(S, d, filterWidth));
 }
 
 // Shadow query of one light from shade point Q (light.cpp:14-31,66-98,112-149):
@@ -592,14 +656,15 @@ __device__ __forceinline__ V3 lightIntensityFrom(const DevScene& S, const RtLigh
 // the wavefronts that hide the traversal's memory latency).
 template <bool FAST, bool STATS, bool TRI>
 __global__ void RT_TRACE_BOUNDS(FAST, TRI)
-k_shadow(DevScene S, int nMax, size_t spOff, Pool P) {
-  // grid: x over the shade points of the level (at most nMax), y = light
-  const long long sIdx = xcdBlock() * blockDim.x + threadIdx.x;
-  const unsigned int nsp = P.counters->nsp;
+k_shadow(DevScene S, Pool P) {
+  // grid: x over the shade points of the level, y = light
+  const long long nsp = shadePointsOf(P);
+  checkCoverage(P.counters, (long long)gridDim.x * blockDim.x, nsp);
+  const size_t spOff = P.counters->spOff;
+  const long long s = xcdBlock() * blockDim.x + threadIdx.x;
   TraceCounters tc{0, 0};
-  if (sIdx < nMax && sIdx < (long long)nsp) {
+  if (s < nsp) {
     const int li = (int)blockIdx.y;
-    const int s = (int)sIdx;
     if ((unsigned int)P.spMat[spOff + s] & RT_SPM_LIT) {
       const V3 Q = loadV3(P.spQ, P.cap, spOff + s);
       int prim;
@@ -689,11 +754,13 @@ __device__ __forceinline__ void shadePoint(const DevScene& S, const Pool& P, int
 // pass was measured slower: a thread there walks up to 16 points one after the
 // other, and pow / acos want the parallelism of a dense launch.)
 __global__ void __launch_bounds__(kBlock)
-k_lights(DevScene S, int nMax, size_t spOff, Pool P) {
-  const int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= nMax || (unsigned int)s >= P.counters->nsp) return;
-  const size_t g = spOff + s;
-  shadePoint(S, P, s, g, (unsigned int)P.spMat[g], loadV3(P.spQ, P.cap, g), loadV3(P.spN, P.cap, g));
+k_lights(DevScene S, Pool P) {
+  const long long nsp = shadePointsOf(P);
+  checkCoverage(P.counters, (long long)gridDim.x * blockDim.x, nsp);
+  const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= nsp) return;
+  const size_t g = (size_t)P.counters->spOff + s;
+  shadePoint(S, P, (int)s, g, (unsigned int)P.spMat[g], loadV3(P.spQ, P.cap, g), loadV3(P.spN, P.cap, g));
 }
 
 // The secondary rays of RayTracer::traceRay (RayTracer.cpp:152-201).  Reflected rays of a tile are
@@ -703,124 +770,133 @@ k_lights(DevScene S, int nMax, size_t spOff, Pool P) {
 // latency-bound kernel a third of its resident wavefronts even when it never runs.
 template <bool REFR>
 __global__ void __launch_bounds__(kBlock)
-k_shade(DevScene S, int nMax, int items, int par, RaySrc R, size_t spOff, size_t rayOff, size_t nextRayOff,
-        int depthLeft, Pool P) {
+k_shade(DevScene S, int items, int par, RaySrc R, int depthLeft, Pool P) {
   __shared__ TileScan ts;
   __shared__ unsigned int litCount;
-  const unsigned int nsp = min((unsigned int)nMax, P.counters->nsp);
-  const int tileBase = blockIdx.x * kBlock * items;
-  if ((unsigned int)tileBase >= nsp) return;   // whole block, uniform
-  // pass 1: which children each shade point spawns (and how many points are lit)
-  unsigned int reflMask = 0, refrMask = 0, myLit = 0;
-  for (int k = 0; k < items; k++) {
-    const int s = tileBase + k * kBlock + threadIdx.x;
-    bool wantRefl = false, wantRefr = false;
-    if ((unsigned int)s < nsp) {
+  const long long nsp = shadePointsOf(P);
+  const size_t spOff = P.counters->spOff, rayOff = P.counters->rayOff;
+  const size_t nextRayOff = rayOff + P.counters->n;
+  const long long perTile = (long long)kBlock * items;
+  checkCoverage(P.counters, gridDim.x * perTile, nsp);
+  const long long tileBase = blockIdx.x * perTile;
+  if (tileBase >= nsp) return;   // whole block, uniform
+  {
+    // pass 1: which children each shade point spawns (and how many points are lit)
+    unsigned int reflMask = 0, refrMask = 0, myLit = 0;
+    for (int k = 0; k < items; k++) {
+      const long long s = tileBase + k * kBlock + threadIdx.x;
+      bool wantRefl = false, wantRefr = false;
+      if (s < nsp) {
+        const size_t g = spOff + s;
+        const unsigned int mw = (unsigned int)P.spMat[g];
+        const bool interp = (mw & RT_SPM_INTERP) != 0;
+        const DevMat* dm = interp ? nullptr : &S.devMats[mw & RT_SPM_INDEX];
+        if (mw & RT_SPM_LIT) myLit++;
+        if (depthLeft > 0) {
+          wantRefl = interp ? !iszero(loadV3(P.spKr, P.cap, g)) : (dm->flags & RT_MATF_KR) != 0;
+          if (REFR && (interp ? !iszero(loadV3(P.spKt, P.cap, g)) : (dm->flags & RT_MATF_KT) != 0)) {
+            V3 p, d;
+            rayOf(S, R, (int)((size_t)P.spRayGlobal[g] - rayOff), p, d);
+            const double cosineAngle = acos(dot(loadV3(P.spN, P.cap, g), d)) * 180 / M_PI;
+            wantRefr = cosineAngle < 360;  // RayTracer.cpp:173,195: false only for a NaN angle
+          }
+        } else {
+          P.spChildRefl[g] = -1;
+          P.spChildRefr[g] = -1;
+        }
+      }
+      reflMask |= (wantRefl ? 1u : 0u) << k;
+      refrMask |= (wantRefr ? 1u : 0u) << k;
+      tileCount(ts, 0, k, wantRefl);
+      if (REFR) tileCount(ts, 1, k, wantRefr);
+    }
+    if (threadIdx.x == 0) litCount = 0;
+    unsigned int nRefl = 0, nRefr = 0;
+    tileReserve(ts, items, REFR ? 2 : 1, &P.counters->nnext, nRefl, nRefr);   // has barriers before and after the scan
+    if (myLit) atomicAdd(&litCount, myLit);                         // LDS atomic
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      if (nRefl) atomicAdd(&P.counters->refl, (unsigned long long)nRefl);
+      if (nRefr) atomicAdd(&P.counters->refr, (unsigned long long)nRefr);
+      if (litCount) atomicAdd(&P.counters->litsp, (unsigned long long)litCount);
+    }
+    if (depthLeft <= 0) return;
+    // pass 2: generate the rays into their slots
+    const int np = par ^ 1;
+    for (int k = 0; k < items; k++) {
+      const long long s = tileBase + k * kBlock + threadIdx.x;
+      const bool wantRefl = (reflMask >> k) & 1u, wantRefr = REFR && ((refrMask >> k) & 1u);
+      const unsigned int a = tileSlot(ts, 0, k, wantRefl);
+      const unsigned int b = REFR ? tileSlot(ts, 1, k, wantRefr) : 0u;
+      if (s >= nsp) continue;
       const size_t g = spOff + s;
-      const unsigned int mw = (unsigned int)P.spMat[g];
-      const bool interp = (mw & RT_SPM_INTERP) != 0;
-      const DevMat* dm = interp ? nullptr : &S.devMats[mw & RT_SPM_INDEX];
-      if (mw & RT_SPM_LIT) myLit++;
-      if (depthLeft > 0) {
-        wantRefl = interp ? !iszero(loadV3(P.spKr, P.cap, g)) : (dm->flags & RT_MATF_KR) != 0;
-        if (REFR && (interp ? !iszero(loadV3(P.spKt, P.cap, g)) : (dm->flags & RT_MATF_KT) != 0)) {
-          V3 p, d;
-          rayOf(S, R, (int)((size_t)P.spRayGlobal[g] - rayOff), p, d);
-          const double cosineAngle = acos(dot(loadV3(P.spN, P.cap, g), d)) * 180 / M_PI;
-          wantRefr = cosineAngle < 360;  // RayTracer.cpp:173,195: false only for a NaN angle
+      int childRefl = -1, childRefr = -1;
+      if (wantRefl || wantRefr) {
+        V3 p, d;
+        rayOf(S, R, (int)((size_t)P.spRayGlobal[g] - rayOff), p, d);
+        const V3 N = loadV3(P.spN, P.cap, g);
+        const V3 Q = loadV3(P.spQ, P.cap, g);
+        const V3 minusD = -1 * d;
+        const V3 cosVector = N * dot(minusD, N);
+        const V3 sinVector = cosVector + d;
+        if (wantRefl) {
+          if (nextRayOff + a >= P.cap) {
+            P.counters->overflow = RT_OVERFLOW_POOL;
+          } else {
+            const V3 reflDir = normalized(cosVector + sinVector);
+            storeV3(P.rayP[np], P.cap, a, Q);
+            storeV3(P.rayD[np], P.cap, a, reflDir);
+            P.rayType[np][a] = RT_RAY_REFLECTION;
+            childRefl = (int)(nextRayOff + a);
+          }
         }
-      } else {
-        P.spChildRefl[g] = -1;
-        P.spChildRefr[g] = -1;
+        if (wantRefr) {
+          if (nextRayOff + b >= P.cap) {
+            P.counters->overflow = RT_OVERFLOW_POOL;
+          } else {
+            const unsigned int mw = (unsigned int)P.spMat[g];
+            const double ior = (mw & RT_SPM_INTERP) ? P.spIor[g] : S.devMats[mw & RT_SPM_INDEX].ior;
+            const double cosineAngle = acos(dot(N, d)) * 180 / M_PI;
+            double n_i, n_r;
+            int iDirection;
+            if (cosineAngle > 90) { n_i = 1; n_r = ior; iDirection = 1; }
+            else { n_i = ior; n_r = 1; iDirection = -1; }
+            const V3 sinT = (n_i / n_r) * sinVector;
+            const V3 cosT = (-1 * N) * sqrt(1 - dot(sinT, sinT));
+            const V3 rd = normalized(cosT + (double)iDirection * sinT);
+            storeV3(P.rayP[np], P.cap, b, Q);
+            storeV3(P.rayD[np], P.cap, b, (double)iDirection * rd);
+            P.rayType[np][b] = RT_RAY_REFRACTION;
+            childRefr = (int)(nextRayOff + b);
+          }
+        }
       }
+      P.spChildRefl[g] = childRefl;
+      P.spChildRefr[g] = childRefr;
     }
-    reflMask |= (wantRefl ? 1u : 0u) << k;
-    refrMask |= (wantRefr ? 1u : 0u) << k;
-    tileCount(ts, 0, k, wantRefl);
-    if (REFR) tileCount(ts, 1, k, wantRefr);
-  }
-  if (threadIdx.x == 0) litCount = 0;
-  unsigned int nRefl = 0, nRefr = 0;
-  tileReserve(ts, items, REFR ? 2 : 1, &P.counters->nnext, nRefl, nRefr);   // has barriers before and after the scan
-  if (myLit) atomicAdd(&litCount, myLit);                         // LDS atomic
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    if (nRefl) atomicAdd(&P.counters->refl, (unsigned long long)nRefl);
-    if (nRefr) atomicAdd(&P.counters->refr, (unsigned long long)nRefr);
-    if (litCount) atomicAdd(&P.counters->litsp, (unsigned long long)litCount);
-  }
-  if (depthLeft <= 0) return;
-  // pass 2: generate the rays into their slots
-  const int np = par ^ 1;
-  for (int k = 0; k < items; k++) {
-    const int s = tileBase + k * kBlock + threadIdx.x;
-    const bool wantRefl = (reflMask >> k) & 1u, wantRefr = REFR && ((refrMask >> k) & 1u);
-    const unsigned int a = tileSlot(ts, 0, k, wantRefl);
-    const unsigned int b = REFR ? tileSlot(ts, 1, k, wantRefr) : 0u;
-    if ((unsigned int)s >= nsp) continue;
-    const size_t g = spOff + s;
-    int childRefl = -1, childRefr = -1;
-    if (wantRefl || wantRefr) {
-      V3 p, d;
-      rayOf(S, R, (int)((size_t)P.spRayGlobal[g] - rayOff), p, d);
-      const V3 N = loadV3(P.spN, P.cap, g);
-      const V3 Q = loadV3(P.spQ, P.cap, g);
-      const V3 minusD = -1 * d;
-      const V3 cosVector = N * dot(minusD, N);
-      const V3 sinVector = cosVector + d;
-      if (wantRefl) {
-        if (nextRayOff + a >= P.cap) {
-          P.counters->overflow = 1;
-        } else {
-          const V3 reflDir = normalized(cosVector + sinVector);
-          storeV3(P.rayP[np], P.cap, a, Q);
-          storeV3(P.rayD[np], P.cap, a, reflDir);
-          P.rayType[np][a] = RT_RAY_REFLECTION;
-          childRefl = (int)(nextRayOff + a);
-        }
-      }
-      if (wantRefr) {
-        if (nextRayOff + b >= P.cap) {
-          P.counters->overflow = 1;
-        } else {
-          const unsigned int mw = (unsigned int)P.spMat[g];
-          const double ior = (mw & RT_SPM_INTERP) ? P.spIor[g] : S.devMats[mw & RT_SPM_INDEX].ior;
-          const double cosineAngle = acos(dot(N, d)) * 180 / M_PI;
-          double n_i, n_r;
-          int iDirection;
-          if (cosineAngle > 90) { n_i = 1; n_r = ior; iDirection = 1; }
-          else { n_i = ior; n_r = 1; iDirection = -1; }
-          const V3 sinT = (n_i / n_r) * sinVector;
-          const V3 cosT = (-1 * N) * sqrt(1 - dot(sinT, sinT));
-          const V3 rd = normalized(cosT + (double)iDirection * sinT);
-          storeV3(P.rayP[np], P.cap, b, Q);
-          storeV3(P.rayD[np], P.cap, b, (double)iDirection * rd);
-          P.rayType[np][b] = RT_RAY_REFRACTION;
-          childRefr = (int)(nextRayOff + b);
-        }
-      }
-    }
-    P.spChildRefl[g] = childRefl;
-    P.spChildRefr[g] = childRefr;
   }
 }
 
 // intensity = shade; += kr*traceRay(reflected); += kt*traceRay(refracted)
+// (P.counters: the block of the level that is being combined)
 __global__ void __launch_bounds__(kBlock)
-k_combine(DevScene S, size_t spOff, int nsp, Pool P) {
-  const int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= nsp) return;
-  const size_t g = spOff + s;
-  V3 I = loadV3(P.spShade, P.cap, g);
-  const int cr = P.spChildRefl[g], ct = P.spChildRefr[g];
-  if (cr >= 0 || ct >= 0) {
-    const unsigned int mw = (unsigned int)P.spMat[g];
-    const bool interp = (mw & RT_SPM_INTERP) != 0;
-    const DevMat* dm = interp ? nullptr : &S.devMats[mw & RT_SPM_INDEX];
-    if (cr >= 0) I = I + prod(interp ? loadV3(P.spKr, P.cap, g) : V3(dm->kr), loadV3(P.rayI, P.cap, (size_t)cr));
-    if (ct >= 0) I = I + prod(interp ? loadV3(P.spKt, P.cap, g) : V3(dm->kt), loadV3(P.rayI, P.cap, (size_t)ct));
+k_combine(DevScene S, Pool P) {
+  const long long nsp = shadePointsOf(P);
+  checkCoverage(P.counters, (long long)gridDim.x * blockDim.x, nsp);
+  const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s < nsp) {
+    const size_t g = (size_t)P.counters->spOff + s;
+    V3 I = loadV3(P.spShade, P.cap, g);
+    const int cr = P.spChildRefl[g], ct = P.spChildRefr[g];
+    if (cr >= 0 || ct >= 0) {
+      const unsigned int mw = (unsigned int)P.spMat[g];
+      const bool interp = (mw & RT_SPM_INTERP) != 0;
+      const DevMat* dm = interp ? nullptr : &S.devMats[mw & RT_SPM_INDEX];
+      if (cr >= 0) I = I + prod(interp ? loadV3(P.spKr, P.cap, g) : V3(dm->kr), loadV3(P.rayI, P.cap, (size_t)cr));
+      if (ct >= 0) I = I + prod(interp ? loadV3(P.spKt, P.cap, g) : V3(dm->kt), loadV3(P.rayI, P.cap, (size_t)ct));
+    }
+    storeV3(P.rayI, P.cap, (size_t)P.spRayGlobal[g], I);
   }
-  storeV3(P.rayI, P.cap, (size_t)P.spRayGlobal[g], I);
 }
 
 // RayTracer::trace's clamp, tracePixel / tracePixelAntiAlias's byte conversion
@@ -1047,7 +1123,14 @@ struct RtScene {
   size_t eventsUsed = 0;
   std::vector<unsigned char> eventKind;   // per pair: 0 k_trace, 1 k_lights
   hipEvent_t evStart = nullptr, evStop = nullptr;
-  Counters* countersHost = nullptr;   // pinned: the per-level read-back of the queue sizes
+  Counters* countersHost = nullptr;   // pinned: the read-back of the counter blocks (kCounterBlocks of them)
+  // Share of a batch's primary samples that each recursion level held in the
+  // batch before ([0]: frame batches, [1]: pixel-list batches): what the next
+  // batch sizes its grids from.
+  struct LevelHistory { int depth = -1, ns = 0; std::vector<double> share; };
+  LevelHistory levelHist[2];
+  std::vector<unsigned int> levelN = std::vector<unsigned int>(kCounterBlocks, 0u);   // level-sync batches: rays per level
+  int levelSyncMode = 0;              // RT_AMD_LEVEL_SYNC=1: read every level's count back before the next
 
   ~RtScene() {
     if (stream) hipStreamSynchronize(stream);
@@ -1232,25 +1315,31 @@ struct RenderCtx {
   double usedSlots = 0.0, usedSamples = 0.0;   // pool slots the frame's batches needed, for their samples
 };
 
+// Blocks of `threads` for an estimated `est` items (at least one, so that a
+// level the estimate takes for empty still checks its coverage).
+inline unsigned int blocksFor(long long est, int threads) {
+  return (unsigned int)std::max<long long>(1, (est + threads - 1) / threads);
+}
+
 template <bool FAST, bool STATS>
-void launchTrace(RtScene* sc, const Pool& P, int n, const RaySrc& R) {
-  const int blocks = (int)(((long long)n + kTraceBlock - 1) / kTraceBlock);
+void launchTrace(RtScene* sc, const Pool& P, long long est, const RaySrc& R) {
+  const unsigned int blocks = blocksFor(est, kTraceBlock);
   const size_t lds = FAST ? (size_t)RT_LDS_STACK_BYTES_CLOSEST * kTraceBlock : 0;
   if (FAST && sc->triOnly)
-    k_trace<FAST, STATS, true><<<blocks, kTraceBlock, lds, sc->stream>>>(sc->dev, n, R, P.hitT, P.hitPrim, P.counters);
+    k_trace<FAST, STATS, true><<<blocks, kTraceBlock, lds, sc->stream>>>(sc->dev, R, P.hitT, P.hitPrim, P.counters);
   else
-    k_trace<FAST, STATS, false><<<blocks, kTraceBlock, lds, sc->stream>>>(sc->dev, n, R, P.hitT, P.hitPrim, P.counters);
+    k_trace<FAST, STATS, false><<<blocks, kTraceBlock, lds, sc->stream>>>(sc->dev, R, P.hitT, P.hitPrim, P.counters);
 }
 template <bool FAST, bool STATS>
-void launchShadow(RtScene* sc, hipStream_t st, const Pool& P, int nMax, size_t spOff) {
-  const dim3 grid((unsigned int)(((long long)nMax + kTraceBlock - 1) / kTraceBlock), (unsigned int)sc->dev.n_lights);
+void launchShadow(RtScene* sc, hipStream_t st, const Pool& P, long long est) {
+  const dim3 grid(blocksFor(est, kTraceBlock), (unsigned int)sc->dev.n_lights);
   // opaque scenes: occlusion queries (4-byte stack entries) except for directional
   // lights, which use them anyway; otherwise closest-hit queries bounded by the light
   const size_t lds = !FAST ? 0 : (size_t)(sc->dev.opaque ? RT_LDS_STACK_BYTES_ANYHIT : RT_LDS_STACK_BYTES_CLOSEST) * kTraceBlock;
   if (FAST && sc->triOnly)
-    k_shadow<FAST, STATS, true><<<grid, kTraceBlock, lds, st>>>(sc->dev, nMax, spOff, P);
+    k_shadow<FAST, STATS, true><<<grid, kTraceBlock, lds, st>>>(sc->dev, P);
   else
-    k_shadow<FAST, STATS, false><<<grid, kTraceBlock, lds, st>>>(sc->dev, nMax, spOff, P);
+    k_shadow<FAST, STATS, false><<<grid, kTraceBlock, lds, st>>>(sc->dev, P);
 }
 
 bool timedBegin(RtScene* sc, hipStream_t st) {
@@ -1272,114 +1361,150 @@ void timedEnd(RtScene* sc, hipStream_t st, int kind) {
 }
 
 // Renders pixel slots [first, first+count) of the frame map.  Returns
-// RT_OK, an error, or +1 when the ray pool overflowed (caller splits the batch).
-int renderBatch(RenderCtx& cx, long long first, int count, long long* slotsUsed) {
+// RT_OK, an error, +1 when the ray pool overflowed (caller splits the batch) or
+// +2 when an estimated grid was too small (caller repeats the batch with
+// forceSync).
+//
+// The whole batch -- every recursion level, the bottom-up pass and the resolve
+// -- is queued without a host round trip: a level's ray and shade-point counts
+// stay on the device (Counters::n / rayOff / spOff, handed on by k_advance) and
+// the grids are sized from estimates, the share of the primary samples that
+// each level held in the batch before (RtScene::levelShare).  One read-back of
+// all counter blocks and ONE stream synchronisation end the batch.  A batch
+// without history (first of a scene, other depth or sampling) reads each
+// level's count back before it sizes the next, as does RT_AMD_LEVEL_SYNC=1.
+int renderBatch(RenderCtx& cx, long long first, int count, long long* slotsUsed, bool forceSync) {
   RtScene* sc = cx.sc;
   const Pool& pool = sc->pool;
   const RtRenderParams& rp = *cx.rp;
   const int ns = cx.fm.ns;
   const long long nSamples = (long long)count * ns;
   if ((size_t)nSamples > pool.cap) return 1;
-  HIP_TRY(hipMemsetAsync(pool.counters, 0, sizeof(Counters) * kCounterBlocks, sc->stream));
+  const int nLevels = rp.depth + 1;
+  const int histKey = (cx.fm.pixelList ? 1 : 0);
+  RtScene::LevelHistory& hist = sc->levelHist[histKey];
+  const bool haveHist = hist.depth == rp.depth && hist.ns == ns && (int)hist.share.size() == nLevels;
+  const bool levelSync = !haveHist || forceSync || sc->levelSyncMode == 1;
+  HIP_TRY(hipMemsetAsync(pool.counters, 0, sizeof(Counters) * (size_t)(nLevels + 1), sc->stream));
+  k_begin<<<1, 1, 0, sc->stream>>>(pool.counters, (unsigned int)nSamples);
   // A level's shadow queries and shading depend on its shade points only, the
   // next level's rays on neither: they go to the side stream and run beside the
   // main stream's k_shade of this level and k_trace / k_classify / k_surface of
   // the next.  A thin level spends much of its time waiting for the dependent
   // loads of its longest rays, and the shadow rays of the level above fill those
   // gaps: 3 % of a 4K frame, 8 % of an eighth of it (one rank's share on 8 GPUs).
-  // RT_AMD_OVERLAP=0 keeps one stream (kernel durations without a neighbour);
-  // so do runs that collect traversal counters: the per-level read-back carries
-  // the shadow kernel's counters too.
-  const bool overlap = sc->dev.n_lights > 0 && !cx.wantStats && sc->overlapMode != 0;
+  // RT_AMD_OVERLAP=0 keeps one stream (kernel durations without a neighbour).
+  const bool overlap = sc->dev.n_lights > 0 && sc->overlapMode != 0;
   hipStream_t lightStream = overlap ? sc->side : sc->stream;
   bool sidePending = false;
-  std::vector<LevelInfo> levels;
-  int n = (int)nSamples, par = 0;
-  size_t rayOff = 0, spOff = 0;
-  unsigned long long litTotal = 0, nodes = 0, prims = 0, refl = 0, refr = 0, snodes = 0, sprims = 0;
-  for (int level = 0; level <= rp.depth && n > 0; level++) {
-    Pool P = pool;   // this level's view of the pool: its own counter block
-    P.counters = pool.counters + (level % kCounterBlocks);
-    if (level >= kCounterBlocks) {
-      // the block is reused: the side stream may still read its old contents
-      if (sidePending) HIP_TRY(hipStreamWaitEvent(sc->stream, sc->evSide, 0));
-      HIP_TRY(hipMemsetAsync(P.counters, 0, sizeof(Counters), sc->stream));
+  int par = 0, levelsRun = 0;
+  long long est = nSamples;     // rays the level is sized for (exact with levelSync)
+  for (int level = 0; level < nLevels; level++) {
+    if (level > 0) {
+      if (levelSync) {
+        HIP_TRY(hipMemcpyAsync(sc->countersHost, pool.counters + level, sizeof(Counters), hipMemcpyDeviceToHost, sc->stream));
+        HIP_TRY(hipStreamSynchronize(sc->stream));
+        if (sc->countersHost[0].overflow) {
+          if (sidePending) HIP_TRY(hipStreamSynchronize(sc->side));
+          return (sc->countersHost[0].overflow & RT_OVERFLOW_POOL) ? 1 : 2;
+        }
+        est = (long long)sc->countersHost[0].n;
+        if (est == 0) break;
+      } else {
+        // a quarter above the share the level had last time, never less than a block
+        est = (long long)(hist.share[level] * 1.25 * (double)nSamples) + 256;
+      }
     }
+    levelsRun = level + 1;
+    sc->levelN[(size_t)level] = (unsigned int)std::min<long long>(est, 0x7fffffff);
+    Pool P = pool;   // this level's view of the pool: its own counter block
+    P.counters = pool.counters + level;
     RaySrc R;
     R.p = P.rayP[par]; R.d = P.rayD[par]; R.type = P.rayType[par]; R.stride = P.cap;
     R.primary = level == 0 ? 1 : 0;
     R.fm = cx.fm;
     R.first = makeSlotBase(cx.fm, first);
     const bool timed = timedBegin(sc, sc->stream);
-    if (cx.fast) { if (cx.wantStats) launchTrace<true, true>(sc, P, n, R); else launchTrace<true, false>(sc, P, n, R); }
-    else { if (cx.wantStats) launchTrace<false, true>(sc, P, n, R); else launchTrace<false, false>(sc, P, n, R); }
+    if (cx.fast) { if (cx.wantStats) launchTrace<true, true>(sc, P, est, R); else launchTrace<true, false>(sc, P, est, R); }
+    else { if (cx.wantStats) launchTrace<false, true>(sc, P, est, R); else launchTrace<false, false>(sc, P, est, R); }
     if (timed) timedEnd(sc, sc->stream, 0);
     cx.stats.trace_launches++;
     // entries per thread: enough tiles to fill the chip, few enough atomics
-    const int items = std::min(kMaxItems, std::max(1, n / (kBlock * 2048)));
-    const int tiles = (n + kBlock * items - 1) / (kBlock * items);
-    k_classify<<<tiles, kBlock, 0, sc->stream>>>(n, items, rayOff, spOff, level, P);
-    if (sc->hasFaces) k_surface<<<gridFor(n), kBlock, 0, sc->stream>>>(sc->dev, n, R, rayOff, spOff, level, P);
-    if (sc->surfaceRest)
-      k_surface_rest<<<gridFor(n), kBlock, 0, sc->stream>>>(sc->dev, n, R, rayOff, spOff, level, P);
+    const int items = (int)std::min<long long>(kMaxItems, std::max<long long>(1, est / (kBlock * 2048)));
+    const unsigned int tiles = blocksFor(est, kBlock * items);
+    const unsigned int dense = blocksFor(est, kBlock);
+    k_classify<<<tiles, kBlock, 0, sc->stream>>>(items, level, P);
+    if (sc->hasFaces) k_surface<<<dense, kBlock, 0, sc->stream>>>(sc->dev, R, level, P);
+    if (sc->surfaceRest) k_surface_rest<<<dense, kBlock, 0, sc->stream>>>(sc->dev, R, level, P);
     if (rp.use_cubemap && sc->dev.cube_w > 0)
-      k_background<<<gridFor(n), kBlock, 0, sc->stream>>>(sc->dev, n, R, rayOff, rp.filter_width, P);
+      k_background<<<dense, kBlock, 0, sc->stream>>>(sc->dev, R, rp.filter_width, P);
     if (overlap) {
       HIP_TRY(hipEventRecord(sc->evSurface, sc->stream));
       HIP_TRY(hipStreamWaitEvent(sc->side, sc->evSurface, 0));
     }
     if (sc->dev.n_lights > 0) {
       const bool timed2 = timedBegin(sc, lightStream);
-      if (cx.fast) { if (cx.wantStats) launchShadow<true, true>(sc, lightStream, P, n, spOff); else launchShadow<true, false>(sc, lightStream, P, n, spOff); }
-      else { if (cx.wantStats) launchShadow<false, true>(sc, lightStream, P, n, spOff); else launchShadow<false, false>(sc, lightStream, P, n, spOff); }
+      if (cx.fast) { if (cx.wantStats) launchShadow<true, true>(sc, lightStream, P, est); else launchShadow<true, false>(sc, lightStream, P, est); }
+      else { if (cx.wantStats) launchShadow<false, true>(sc, lightStream, P, est); else launchShadow<false, false>(sc, lightStream, P, est); }
       if (timed2) timedEnd(sc, lightStream, 1);
       cx.stats.lights_launches++;
     }
-    k_lights<<<gridFor(n), kBlock, 0, lightStream>>>(sc->dev, n, spOff, P);
+    k_lights<<<dense, kBlock, 0, lightStream>>>(sc->dev, P);
     if (overlap) {
       HIP_TRY(hipEventRecord(sc->evSide, sc->side));
       sidePending = true;
     }
     if (sc->dev.opaque)
-      k_shade<false><<<tiles, kBlock, 0, sc->stream>>>(sc->dev, n, items, par, R, spOff, rayOff, rayOff + n,
-                                                       rp.depth - level, P);
+      k_shade<false><<<tiles, kBlock, 0, sc->stream>>>(sc->dev, items, par, R, rp.depth - level, P);
     else
-      k_shade<true><<<tiles, kBlock, 0, sc->stream>>>(sc->dev, n, items, par, R, spOff, rayOff, rayOff + n,
-                                                      rp.depth - level, P);
-    HIP_TRY(hipMemcpyAsync(sc->countersHost, P.counters, sizeof(Counters), hipMemcpyDeviceToHost, sc->stream));
-    HIP_TRY(hipStreamSynchronize(sc->stream));
-    const Counters c = *sc->countersHost;
-    if (c.overflow) {
-      if (sidePending) HIP_TRY(hipStreamSynchronize(sc->side));
-      return 1;
-    }
-    levels.push_back({rayOff, spOff, n, (int)c.nsp});
-    litTotal += c.litsp;
-    nodes += c.nodes;
-    prims += c.prims;
-    snodes += c.shadowNodes;
-    sprims += c.shadowPrims;
-    refl += c.refl;
-    refr += c.refr;
-    rayOff += n;
-    spOff += c.nsp;
-    n = (int)c.nnext;
+      k_shade<true><<<tiles, kBlock, 0, sc->stream>>>(sc->dev, items, par, R, rp.depth - level, P);
+    k_advance<<<1, 1, 0, sc->stream>>>(P.counters, (unsigned int)pool.cap);
     par ^= 1;
   }
   // the colours of every level's shade points are needed from here on
   if (sidePending) HIP_TRY(hipStreamWaitEvent(sc->stream, sc->evSide, 0));
-  const Pool& P = pool;
-  for (int li = (int)levels.size() - 1; li >= 0; li--) {
-    const LevelInfo& L = levels[li];
-    if (L.nsp > 0) k_combine<<<gridFor(L.nsp), kBlock, 0, sc->stream>>>(sc->dev, L.spOff, L.nsp, P);
+  for (int level = levelsRun - 1; level >= 0; level--) {
+    Pool P = pool;
+    P.counters = pool.counters + level;
+    k_combine<<<blocksFor((long long)sc->levelN[(size_t)level], kBlock), kBlock, 0, sc->stream>>>(sc->dev, P);
   }
   {
     const int pitch = ns | 1;
     const int ppb = std::max(1, std::min(kBlock, kResolveSamples / pitch));
-    k_resolve<<<(count + ppb - 1) / ppb, kBlock, 0, sc->stream>>>(cx.fm, makeSlotBase(cx.fm, first), count, ppb, P, cx.rgbDev,
+    k_resolve<<<(count + ppb - 1) / ppb, kBlock, 0, sc->stream>>>(cx.fm, makeSlotBase(cx.fm, first), count, ppb, pool, cx.rgbDev,
                                                                     cx.hitDev, cx.tileOffDev);
   }
   HIP_TRY(hipGetLastError());
+  // the batch's one read-back: every level's counter block, and the block the
+  // last level's k_advance wrote (overflow seen anywhere ends up there)
+  HIP_TRY(hipMemcpyAsync(sc->countersHost, pool.counters, sizeof(Counters) * (size_t)(levelsRun + 1), hipMemcpyDeviceToHost,
+                         sc->stream));
+  HIP_TRY(hipStreamSynchronize(sc->stream));
+  const Counters* c = sc->countersHost;
+  {
+    unsigned int flags = 0;
+    for (int l = 0; l <= levelsRun; l++) flags |= c[l].overflow;
+    if (flags & RT_OVERFLOW_POOL) return 1;
+    if (flags) return 2;
+  }
+  unsigned long long litTotal = 0, nodes = 0, prims = 0, refl = 0, refr = 0, snodes = 0, sprims = 0;
+  size_t rayEnd = 0, spEnd = 0;
+  hist.share.assign((size_t)nLevels, 0.0);
+  for (int l = 0; l < levelsRun; l++) {
+    litTotal += c[l].litsp;
+    nodes += c[l].nodes;
+    prims += c[l].prims;
+    snodes += c[l].shadowNodes;
+    sprims += c[l].shadowPrims;
+    refl += c[l].refl;
+    refr += c[l].refr;
+    cx.stats.shade_points += (unsigned long long)c[l].nsp;
+    rayEnd = (size_t)c[l].rayOff + c[l].n;
+    spEnd = (size_t)c[l].spOff + c[l].nsp;
+    hist.share[(size_t)l] = (double)c[l].n / (double)nSamples;
+  }
+  hist.depth = rp.depth;
+  hist.ns = ns;
   // stats: dead (out-of-frame) slots are not rays
   cx.stats.rays_reflect += refl;
   cx.stats.rays_refract += refr;
@@ -1388,9 +1513,8 @@ int renderBatch(RenderCtx& cx, long long first, int count, long long* slotsUsed)
   cx.stats.prims_tested += prims + sprims;
   cx.stats.shadow_nodes_visited += snodes;
   cx.stats.shadow_prims_tested += sprims;
-  for (const LevelInfo& L : levels) cx.stats.shade_points += (unsigned long long)L.nsp;
   cx.stats.batches++;
-  *slotsUsed = (long long)std::max(rayOff, spOff);
+  *slotsUsed = (long long)std::max(rayEnd, spEnd);
   return RT_OK;
 }
 
@@ -1413,10 +1537,18 @@ int renderRange(RenderCtx& cx, long long first, long long count) {
   const long long end = first + count;
   long long limit = std::numeric_limits<long long>::max();
   long long b = first;
+  bool forceSync = false;
   while (b < end) {
     const int c = (int)std::min(std::min(batchFor(cx), limit), end - b);
     long long used = 0;
-    int rc = renderBatch(cx, b, c, &used);
+    int rc = renderBatch(cx, b, c, &used, forceSync);
+    if (rc == 2 && !forceSync) {   // a level outgrew its estimate: once more, sized level by level
+      forceSync = true;
+      cx.stats.batches_redone++;
+      continue;
+    }
+    forceSync = false;
+    if (rc == 2) return fail(RT_ERR_DEVICE, "a level outgrew a grid sized from its exact count");
     if (rc == 1) {
       if (c <= 64) return fail(RT_ERR_NOMEM, "ray pool too small for a 64-pixel batch");
       HIP_TRY(hipStreamSynchronize(sc->stream));
@@ -1566,7 +1698,8 @@ int rt_scene_create(const RtSceneDesc* d, RtScene** out) {
   HIP_TRY(hipEventCreateWithFlags(&sc->evSurface, hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&sc->evSide, hipEventDisableTiming));
   if (const char* e = std::getenv("RT_AMD_OVERLAP")) sc->overlapMode = std::atoi(e) != 0 ? 1 : 0;
-  HIP_TRY(hipHostMalloc((void**)&sc->countersHost, sizeof(Counters), hipHostMallocDefault));
+  HIP_TRY(hipHostMalloc((void**)&sc->countersHost, sizeof(Counters) * kCounterBlocks, hipHostMallocDefault));
+  if (const char* e = std::getenv("RT_AMD_LEVEL_SYNC")) sc->levelSyncMode = std::atoi(e) != 0 ? 1 : 0;
   HIP_TRY(hipEventCreate(&sc->evStart));
   HIP_TRY(hipEventCreate(&sc->evStop));
   DevScene& D = sc->dev;
@@ -1918,6 +2051,7 @@ int rt_render(RtScene* sc, const RtRenderParams* rp, unsigned char* rgb8_out, in
               RtStats* stats_out) {
   if (!sc || !rp || !rgb8_out) return fail(RT_ERR_INVALID, "null argument");
   if (rp->width <= 0 || rp->height <= 0 || rp->depth < 0) return fail(RT_ERR_INVALID, "bad frame size or depth");
+  if (rp->depth > kMaxDepth) return fail(RT_ERR_UNSUPPORTED, "recursion depth above 126");
   if (rp->tile_w <= 0 || rp->tile_h <= 0 || (rp->tile_w & 7) || (rp->tile_h & 7))
     return fail(RT_ERR_INVALID, "tile_w and tile_h must be positive multiples of 8");
   if (rp->shard_count <= 0 || rp->shard_index < 0 || rp->shard_index >= rp->shard_count)
@@ -2073,6 +2207,7 @@ int rt_render_pixels(RtScene* sc, const RtRenderParams* rp, int n_pixels, const 
                      RtStats* stats_out) {
   if (!sc || !rp || n_pixels < 0 || (n_pixels > 0 && (!xy || !rgb8_out))) return fail(RT_ERR_INVALID, "null argument");
   if (rp->width <= 0 || rp->height <= 0 || rp->depth < 0) return fail(RT_ERR_INVALID, "bad frame size or depth");
+  if (rp->depth > kMaxDepth) return fail(RT_ERR_UNSUPPORTED, "recursion depth above 126");
   if (rp->aa_mode != RT_AA_NONE && (rp->aa_samples < 1 || rp->aa_samples > 8))
     return fail(RT_ERR_INVALID, "aa_samples must be 1..8");
   if (rp->traversal != RT_TRAVERSE_REFERENCE && rp->traversal != RT_TRAVERSE_FAST)

@@ -352,3 +352,39 @@ def test_one_stream_and_two_streams_give_the_same_frame(built, monkeypatch):
         ds.close()
     assert np.array_equal(frames[0][0], frames[1][0]) and np.array_equal(frames[0][1], frames[1][1])
     assert frames[0][2:] == frames[1][2:]
+
+
+def test_level_estimates_and_the_redo_of_an_outgrown_batch(built, monkeypatch):
+    """Frames after a scene's first are queued without reading a level's ray
+    count back (grids sized from the shares the batch before had); the frame
+    must equal the one rendered level by level (RT_AMD_LEVEL_SYNC=1).  A batch
+    whose levels outgrow those estimates is redone: sky pixels first (no
+    secondary rays), then the same number of pixels on the reflecting spheres."""
+    hs = host.HostScene(text=scenes.simple_scene())
+    kw = dict(width=128, height=128, depth=3, traversal=abi.RT_TRAVERSE_FAST)
+    frames = []
+    for setting in ("1", "0"):
+        monkeypatch.setenv("RT_AMD_LEVEL_SYNC", setting)
+        ds = device.DeviceScene(hs.desc_ptr)
+        p, _ = host.render_params(**kw)
+        for _ in range(3):
+            rgb, hits, st = ds.render(p)
+            assert st.batches_redone == 0
+        frames.append((rgb, hits, _ray_counts(st), st.shade_points))
+        if setting == "0":
+            ref_rgb, ref_hits, ref_st = loader.render(hs.desc_ptr, p, threads=8)
+            common.assert_parity(rgb, hits, ref_rgb, ref_hits, what="estimated grids")
+            assert _ray_counts(st) == _ray_counts(ref_st)
+            hit = np.argwhere(ref_hits > 0)[:, ::-1].astype(np.int32)      # (x, y) of pixels that hit something
+            sky = np.argwhere(ref_hits == 0)[:, ::-1].astype(np.int32)
+            n = min(len(hit), len(sky), 4000)
+            assert n > 1000
+            a, sa = ds.render_pixels(p, np.ascontiguousarray(sky[:n]))
+            a, sa = ds.render_pixels(p, np.ascontiguousarray(sky[:n]))
+            assert sa.batches_redone == 0 and sa.rays_total == n
+            b, sb = ds.render_pixels(p, np.ascontiguousarray(hit[:n]))
+            assert sb.batches_redone == 1
+            assert np.array_equal(b, ref_rgb[hit[:n, 1], hit[:n, 0]])
+        ds.close()
+    assert np.array_equal(frames[0][0], frames[1][0]) and np.array_equal(frames[0][1], frames[1][1])
+    assert frames[0][2:] == frames[1][2:]

@@ -12,7 +12,9 @@ busy_until = t0
 idle = 0
 for r in frame:
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
-    name = r["Kernel_Name"].split("(")[0].replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "")
+    import re as _re
+    _m = _re.search(r"(k_[a-z_]+)", r["Kernel_Name"])
+    name = _m.group(1) if _m else r["Kernel_Name"].split("(")[0][-30:]
     gap = s - busy_until
     if gap > 0:
         idle += gap
