@@ -226,6 +226,18 @@ int rt_render(RtScene* scene, const RtRenderParams* params,
 int rt_intersect_batch(RtScene* scene, int traversal, int n, const double* rays_pd,
                        const int* ray_types, RtHit* hits);
 
+/* rt_intersect_batch for callers that cannot allocate device memory (code under
+ * HIP graph capture, tight serving loops, harnesses that forbid it).  It has no
+ * counterpart in the reference.  Same arguments and results as
+ * rt_intersect_batch, but rays, types and hit records are staged in an array
+ * that is part of the library's code object instead of per-call hipMalloc'ed
+ * buffers: the call allocates and frees nothing.  At most 65536 rays per call
+ * (more: RT_ERR_INVALID).  Every GPU the library runs on holds its own copy of
+ * the array (7.25 MiB) until the process ends; all calls on one GPU share it,
+ * so calls that overlap on one GPU -- from different threads or scenes -- race. */
+int rt_intersect_batch_static(RtScene* scene, int traversal, int n, const double* rays_pd,
+                              const int* ray_types, RtHit* hits);
+
 /* Number of pixels / bytes of the packed tile buffer of one shard, and the
  * scatter of packed tiles back into a full frame on the device.  Packed layout:
  * the shard's tiles in increasing tile number, each tile row-major, clipped at

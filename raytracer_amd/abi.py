@@ -107,6 +107,7 @@ RT_AMD_SYMBOLS = {
     "rt_render": (C.c_int, [C.c_void_p, C.POINTER(RtRenderParams), C.c_void_p, C.c_void_p,
                             C.POINTER(RtStats)]),
     "rt_intersect_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_int, PD, PI, C.POINTER(RtHit)]),
+    "rt_intersect_batch_static": (C.c_int, [C.c_void_p, C.c_int, C.c_int, PD, PI, C.POINTER(RtHit)]),
     "rt_shard_pixels": (C.c_longlong, [C.c_int] * 6),
     "rt_unpack_tiles": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                   C.c_int, C.c_void_p, C.c_void_p]),

@@ -1093,6 +1093,40 @@ void invert4(const double* m, double* out) {
 
 }  // namespace
 
+// ---- staging memory of rt_intersect_batch_static ------------------------------
+// Rays, ray types and hit records of one call, kRaysStaticMax rays at most, in
+// an array that is part of the code object: every GPU the library runs on holds
+// its own copy (7.25 MiB) until the process ends, and a call that uses it
+// allocates nothing.  In host code the array's name is only a handle for
+// hipGetSymbolAddress; the address it yields for the current device is what
+// kernels and copies are given.
+constexpr int kRaysStaticMax = 65536;
+constexpr size_t kStaticRaysBytes = (size_t)kRaysStaticMax * 6 * sizeof(double);
+constexpr size_t kStaticTypesBytes = (size_t)kRaysStaticMax * sizeof(int);
+constexpr size_t kStaticHitsBytes = (size_t)kRaysStaticMax * sizeof(RtHit);
+static __device__ __align__(256) unsigned char scratch[kStaticRaysBytes + kStaticTypesBytes + kStaticHitsBytes];
+
+namespace {
+constexpr int kMaxDevices = 64;
+std::mutex g_scratchMutex;
+unsigned char* g_scratchPtr[kMaxDevices] = {};   // device address of `scratch` per HIP device
+
+// Looks the array's address up on the CURRENT device, once per device.
+hipError_t scratchOfCurrentDevice(int device, unsigned char** out) {
+  *out = nullptr;
+  if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+  std::lock_guard<std::mutex> lock(g_scratchMutex);
+  if (!g_scratchPtr[device]) {
+    void* ptr = nullptr;
+    const hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+    if (e != hipSuccess) return e;
+    g_scratchPtr[device] = static_cast<unsigned char*>(ptr);
+  }
+  *out = g_scratchPtr[device];
+  return hipSuccess;
+}
+}  // namespace
+
 struct RtScene {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -1684,6 +1718,11 @@ int rt_scene_create(const RtSceneDesc* d, RtScene** out) {
   std::memset(&sc->dev, 0, sizeof sc->dev);
   std::memset(&sc->pool, 0, sizeof sc->pool);
   HIP_TRY(hipGetDevice(&sc->device));
+  {
+    // the static staging array's address on this device (rt_intersect_batch_static)
+    unsigned char* staging = nullptr;
+    HIP_TRY(scratchOfCurrentDevice(sc->device, &staging));
+  }
   // The main stream carries the chain of levels a frame cannot finish before;
   // it gets the higher priority.  (The two priorities also keep the two streams
   // on different hardware queues however many streams the process has made:
@@ -2291,6 +2330,33 @@ int rt_intersect_batch(RtScene* sc, int traversal, int n, const double* rays_pd,
     k_intersect<false><<<gridFor(n), kBlock, 0, sc->stream>>>(sc->dev, n, rays.as<double>(), types.as<int>(), hitBuf.as<RtHit>());
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(hits, hitBuf.p, (size_t)n * sizeof(RtHit), hipMemcpyDeviceToHost, sc->stream));
+  HIP_TRY(hipStreamSynchronize(sc->stream));
+  return RT_OK;
+}
+
+int rt_intersect_batch_static(RtScene* sc, int traversal, int n, const double* rays_pd, const int* ray_types,
+                              RtHit* hits) {
+  if (!sc || n < 0 || (n > 0 && (!rays_pd || !hits))) return fail(RT_ERR_INVALID, "bad argument");
+  if (n > kRaysStaticMax) return fail(RT_ERR_INVALID, "rt_intersect_batch_static takes at most 65536 rays per call");
+  if (n == 0) return RT_OK;
+  HIP_TRY(hipSetDevice(sc->device));
+  unsigned char* base = nullptr;
+  HIP_TRY(scratchOfCurrentDevice(sc->device, &base));   // looked up at rt_scene_create: a table read here
+  double* raysDev = reinterpret_cast<double*>(base);
+  int* typesDev = reinterpret_cast<int*>(base + kStaticRaysBytes);
+  RtHit* hitsDev = reinterpret_cast<RtHit*>(base + kStaticRaysBytes + kStaticTypesBytes);
+  // every byte a launch reads is written by this call first and the kernel writes
+  // every hit record it hands back, so nothing of an earlier call can show through
+  HIP_TRY(hipMemcpyAsync(raysDev, rays_pd, 6 * (size_t)n * sizeof(double), hipMemcpyHostToDevice, sc->stream));
+  if (ray_types) HIP_TRY(hipMemcpyAsync(typesDev, ray_types, (size_t)n * sizeof(int), hipMemcpyHostToDevice, sc->stream));
+  const int* typesArg = ray_types ? typesDev : nullptr;
+  if (traversal == RT_TRAVERSE_FAST)
+    k_intersect<true><<<gridFor(n), kBlock, (size_t)RT_LDS_STACK_BYTES_CLOSEST * kBlock, sc->stream>>>(
+        sc->dev, n, raysDev, typesArg, hitsDev);
+  else
+    k_intersect<false><<<gridFor(n), kBlock, 0, sc->stream>>>(sc->dev, n, raysDev, typesArg, hitsDev);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(hits, hitsDev, (size_t)n * sizeof(RtHit), hipMemcpyDeviceToHost, sc->stream));
   HIP_TRY(hipStreamSynchronize(sc->stream));
   return RT_OK;
 }

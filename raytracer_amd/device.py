@@ -108,6 +108,17 @@ class DeviceScene:
                "rt_intersect_batch")
         return hits
 
+    def intersect_static(self, rays_pd, types=None, traversal=abi.RT_TRAVERSE_REFERENCE):
+        """Scene::intersect through rt_intersect_batch_static (no device allocation, <= 65536 rays)."""
+        rays = np.ascontiguousarray(rays_pd, dtype=np.float64).reshape(-1, 6)
+        n = len(rays)
+        ty = np.ascontiguousarray(types, dtype=np.int32) if types is not None else None
+        hits = (abi.RtHit * n)()
+        _check(lib().rt_intersect_batch_static(self._h, traversal, n, rays.ctypes.data_as(abi.PD),
+                                               ty.ctypes.data_as(abi.PI) if ty is not None else None, hits),
+               "rt_intersect_batch_static")
+        return hits
+
 
 def shard_pixels(width, height, tile_w, tile_h, shard_index, shard_count):
     return lib().rt_shard_pixels(width, height, tile_w, tile_h, shard_index, shard_count)
