@@ -29,6 +29,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak
+# FP64 vector peak with contraction off: the vendor's 78.6 TFLOP/s counts a fused
+# multiply-add as two operations; the path may not fuse (bit parity with the
+# reference's x86-64 arithmetic), so an instruction slot carries one.
+FP64_VALU_PEAK_TFLOPS = 39.3
 TILE = 32
 
 
@@ -58,7 +62,7 @@ def build_scene(name, scale):
     if cfg["aa"]:
         kw.update(aa_mode=abi.RT_AA_FULL, aa_samples=cfg["aa"], jitter=host.jitter_table(1234567, cfg["aa"]))
     d = hs.desc
-    desc = "%s %dx%d depth %d aa %s, %d triangles + %d objects, %d lights, kd depth %d leaf 10 (%d nodes)" % (
+    desc = "%s %dx%d depth %d aa %s, %d triangles + %d objects, %d lights; caller KD-tree: depth %d leaf 10 (%d nodes)" % (
         name, width, height, cfg["depth"], ("%dx%d" % (cfg["aa"], cfg["aa"])) if cfg["aa"] else "off",
         d.n_faces, d.n_objects - d.n_meshes, d.n_lights, cfg["kd_depth"], d.n_nodes)
     log("[bench] scene %s built in %.1f s" % (desc, time.time() - t0))
@@ -89,6 +93,7 @@ def cpu_baseline(hs, width, height, kw, budget_s):
     dt = time.time() - t0
     rays = st.rays_total
     return {"value": round(rays / dt / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "ms_per_step_extrapolated": round(1000.0 * dt * npx / count, 1),
             "sample": "%d of %d pixels (every %d-th, %d rays) of the same frame in %.1f s, "
                       "reference KD traversal, %d std::threads" % (count, npx, stride, rays, dt, cores)}
 
@@ -147,18 +152,31 @@ def main():
                                  shard_index=rank, shard_count=world, out_is_device=True, **kw)
     torch.cuda.synchronize()   # the fills above run on torch's stream, the renders on the library's
     frames_done = [0]
+    # per-frame phases on this rank: host wall time of rt_render (it returns when the
+    # shard is rendered), then torch events around the gather and the unpack
+    phase_events = []
 
-    def step():
+    def step(timed=False):
         k = frames_done[0] % 2
         frames_done[0] += 1
         if packed_free[k] is not None:
             packed_free[k].synchronize()
+        t_r = time.perf_counter()
         st = ds.render_device(p, packed[k].data_ptr())
+        render_ms = (time.perf_counter() - t_r) * 1e3
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if timed else None
+        if ev:
+            ev[0].record()
         bufs = parallel.gather_packed(packed[k], world, rank, force=use_dist, out=gathered)
+        if ev:
+            ev[1].record()
         if rank == 0:
             for r, b in enumerate(bufs):
                 device.unpack_tiles(b.data_ptr(), 3, width, height, TILE, TILE, r, world,
                                     frame.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        if ev:
+            ev[2].record()
+            phase_events.append((render_ms, ev))
         if packed_free[k] is None:
             packed_free[k] = torch.cuda.Event()
         packed_free[k].record()
@@ -176,7 +194,7 @@ def main():
     rays = 0
     sums = np.zeros(6)          # ms_trace, trace launches, ms_lights, lights launches, ms_device, batches
     for _ in range(args.steps):
-        st = step()
+        st = step(timed=True)
         rays += st.rays_total
         sums += [st.ms_trace, st.trace_launches, st.ms_lights, st.lights_launches, st.ms_device, st.batches]
     fence()
@@ -188,16 +206,31 @@ def main():
         dist.all_reduce(cvals, op=dist.ReduceOp.SUM)
     elapsed = float(tvals[0])
     total_rays, trace_ms, trace_n, lights_ms, lights_n, total_dev_ms, total_batches = [float(x) for x in cvals.tolist()]
+    # phases per frame on each rank -> mean and max over ranks (tells compute
+    # imbalance from gather cost in a multi-GPU line)
+    ph = np.array([[r, e[0].elapsed_time(e[1]), e[1].elapsed_time(e[2])] for r, e in phase_events]).mean(axis=0)
+    psum = torch.tensor(ph, dtype=torch.float64, device="cuda")
+    pmax = psum.clone()
+    if use_dist:
+        dist.all_reduce(psum, op=dist.ReduceOp.SUM)
+        dist.all_reduce(pmax, op=dist.ReduceOp.MAX)
+    phases = {}
+    for i, name in enumerate(("render_ms", "gather_ms", "unpack_ms")):
+        phases[name] = {"mean_over_ranks": round(float(psum[i]) / world, 3), "max_over_ranks": round(float(pmax[i]), 3)}
 
-    # Untimed pass with device counters: tree nodes visited (V) and primitives
-    # tested (T), split between the closest-hit kernel (k_trace: primary,
-    # reflection and refraction rays) and the shadow-query kernel
-    # (k_shadow).  Algorithmic bytes of a ray: node_bytes V + 128 T + 160 (node
-    # record: 64 B BVH node on the fast path, 16 B KD node on the reference path;
-    # 128 B triangle record; an 80 B ray record written and read once through the
-    # level queues).  The roofline entry is k_trace, the kernel with the largest
-    # share of the frame; its launch duration comes from HIP events recorded
-    # around every launch on the library's stream during the timed steps.
+    # Untimed pass with device counters: tree nodes visited (V), triangles tested
+    # (T) and non-mesh objects tested (O), split between the closest-hit kernel
+    # (k_trace: primary, reflection and refraction rays) and the shadow-query
+    # kernel (k_shadow).  The roofline entry is k_trace, the kernel with the
+    # largest share of the frame, against the FP64 vector roof: algorithmic
+    # operations of a ray = 8 V + 90 T + 40 O (a plane step of the tree: 8; the
+    # reference's triangle test: 90; the object-space transform of a primitive
+    # test: 40), per launch, over the launch duration that HIP events recorded
+    # around every launch on the library's own stream during the timed steps.
+    # HBM is reported from counters only (a committed rocprofv3 pass of this
+    # command, with the commit it was taken at): the tree is shared by
+    # neighbouring rays and served by the caches, so algorithmic bytes say nothing
+    # about HBM.
     roof = None
     if not args.no_stats_pass:
         ps, keep2 = host.render_params(width, height, traversal=trav, tile_w=TILE, tile_h=TILE,
@@ -205,53 +238,53 @@ def main():
                                        collect_stats=True, **kw)
         torch.cuda.synchronize()
         sst = ds.render_device(ps, packed[0].data_ptr())
-        svals = torch.tensor([float(sst.nodes_visited), float(sst.prims_tested), float(sst.rays_total),
-                              float(sst.shadow_nodes_visited), float(sst.shadow_prims_tested),
-                              float(sst.rays_shadow)], dtype=torch.float64, device="cuda")
+        svals = torch.tensor([float(sst.nodes_visited), float(sst.prims_tested), float(sst.objects_tested),
+                              float(sst.rays_total), float(sst.shadow_nodes_visited), float(sst.shadow_prims_tested),
+                              float(sst.shadow_objects_tested), float(sst.rays_shadow)], dtype=torch.float64, device="cuda")
         if use_dist:
             dist.all_reduce(svals, op=dist.ReduceOp.SUM)
-        V, T, R, Vs, Ts, Rs = [float(x) for x in svals.tolist()]
-        node_bytes = 64.0 if args.traversal == "fast" else 16.0
+        V, T, O, R, Vs, Ts, Os, Rs = [float(x) for x in svals.tolist()]
 
-        def kernel_line(v, t, r, ms, n):
-            frame_bytes = node_bytes * v + 128.0 * t + 160.0 * r
-            per_launch = frame_bytes * args.steps / max(n, 1.0)
+        def kernel_line(v, t, o, r, ms, n):
+            flops_frame = 8.0 * v + 90.0 * t + 40.0 * o
+            per_launch = flops_frame * args.steps / max(n, 1.0)
             ms_launch = ms / max(n, 1.0)
-            ach = per_launch / (ms_launch * 1e-3) / 1e9 if ms_launch > 0 else 0.0
-            return {"bytes_per_ray": round(frame_bytes / max(r, 1.0), 1), "achieved": round(ach, 3),
-                    "bytes_per_launch": round(per_launch), "ms_per_launch": round(ms_launch, 4),
+            ach = per_launch / (ms_launch * 1e-3) / 1e12 if ms_launch > 0 else 0.0
+            return {"flop_per_ray": round(flops_frame / max(r, 1.0), 1), "achieved_TFLOPs": round(ach, 4),
+                    "frac_of_fp64_valu_peak": round(ach / FP64_VALU_PEAK_TFLOPS, 4),
+                    "flop_per_launch": round(per_launch), "ms_per_launch": round(ms_launch, 4),
                     "launches_per_step": round(n / args.steps, 1), "rays_per_step": round(r),
-                    "nodes_per_ray": round(v / max(r, 1.0), 2), "prims_per_ray": round(t / max(r, 1.0), 2),
+                    "nodes_per_ray": round(v / max(r, 1.0), 2), "tris_per_ray": round(t / max(r, 1.0), 2),
+                    "objects_per_ray": round(o / max(r, 1.0), 3),
                     "Grays_per_s": round(r * args.steps / max(ms, 1e-9) / 1e6, 3)}
 
-        kt = kernel_line(V - Vs, T - Ts, R - Rs, trace_ms, trace_n)
-        kl = kernel_line(Vs, Ts, Rs, lights_ms, lights_n)
+        kt = kernel_line(V - Vs, T - Ts, O - Os, R - Rs, trace_ms, trace_n)
+        kl = kernel_line(Vs, Ts, Os, Rs, lights_ms, lights_n)
         traffic = None
-        profiled = {}
+        hbm = None
         tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.config)
         if os.path.exists(tpath) and args.scale == 1.0 and world == 1 and args.traversal == "fast":
             try:
                 tj = json.load(open(tpath))
                 traffic = tj.get("k_trace_hbm_bytes_per_launch")
-                busy, lanes = tj.get("k_trace_valu_busy"), tj.get("k_trace_lanes_active")
-                profiled = {"valu_busy_profiled": busy, "lanes_active_profiled": lanes, "profile": tj.get("source"),
-                            # the VALU roof of the same kernel, from the committed counter pass: share of
-                            # cycles in which a SIMD issues a vector instruction, and of those the
-                            # share of lanes that do work
-                            "valu": {"bound": "valu issue", "issue_busy_frac": busy, "lanes_active_of_64": lanes,
-                                     "frac": round(busy * lanes / 64.0, 4) if busy and lanes else None}}
+                gbs = traffic / (kt["ms_per_launch"] * 1e-3) / 1e9 if traffic and kt["ms_per_launch"] > 0 else None
+                hbm = {"bytes_per_launch_from_counters": traffic,
+                       "achieved_GBs": round(gbs, 1) if gbs else None, "peak_GBs": HBM_PEAK_GBS,
+                       "frac": round(gbs / HBM_PEAK_GBS, 4) if gbs else None,
+                       "source": tj.get("source"), "measured_at_commit": tj.get("commit"),
+                       "counter_pass": {k: tj.get(k) for k in ("k_trace_valu_busy", "k_trace_lanes_active",
+                                                               "k_trace_waves_per_simd")}}
             except Exception:
-                traffic = None
-        roof = {"bound": "hbm",
-                "kernel": "k_trace (%s)" % ("BVH closest-hit traversal" if args.traversal == "fast"
+                traffic, hbm = None, None
+        roof = {"bound": "fp64_valu",
+                "kernel": "k_trace (%s)" % ("closest hit on the library's 4-wide BVH" if args.traversal == "fast"
                                             else "reference KD traversal"),
-                "achieved": kt["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(kt["achieved"] / HBM_PEAK_GBS, 6), "traffic": traffic,
-                "note": "algorithmic bytes are served by L1/L2 (the tree is shared by neighbouring rays): "
-                        "measured HBM traffic is a small fraction of them, the kernel is bound by VALU "
-                        "issue (see valu_busy_profiled) and vector-memory latency, not by HBM",
-                "k_trace": kt, "k_shadow": kl}
-        roof.update(profiled)
+                "achieved": kt["achieved_TFLOPs"], "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": kt["frac_of_fp64_valu_peak"], "traffic": traffic,
+                "note": "FP64 VALU, contraction off; algorithmic operations 8 V + 90 T + 40 O per ray from the "
+                        "in-run counter pass, launch durations from HIP events of the timed steps; traffic = HBM "
+                        "bytes per launch from the committed counter pass named under hbm",
+                "hbm": hbm, "k_trace": kt, "k_shadow": kl}
 
     if rank == 0:
         if args.out:
@@ -260,6 +293,8 @@ def main():
         if args.cpu_seconds > 0 and world == 1:   # the CPU leg belongs to the single-GPU line only
             cpu = cpu_baseline(hs, width, height, kw, args.cpu_seconds)
         value = total_rays / elapsed / 1e6
+        if cpu and cpu["value"] > 0:
+            cpu["gpu_over_cpu"] = round(value / cpu["value"], 1)   # a reported ratio, not a quality measure
         out = {
             "metric": "Mrays/s (primary+secondary+shadow)",
             "value": round(value, 3), "unit": "Mrays/s",
@@ -267,7 +302,11 @@ def main():
             "ms_per_step": round(1000.0 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": desc, "traversal": args.traversal, "tile": TILE,
+            "config": {"workload": desc,
+                       "traversal": ("fast: 4-wide BVH built by the library at scene creation; the caller's KD-tree is "
+                                     "uploaded but not traversed" if args.traversal == "fast"
+                                     else "reference: the caller's KD-tree, Scene::intersectKdTree's rules"),
+                       "tile": TILE, "rccl_ranks": world if use_dist else 0, "phases_per_step": phases,
                        "rays_per_step": round(total_rays / args.steps),
                        "sharding": "interleaved %dx%d tiles over %d rank(s), one gather per frame" % (TILE, TILE, world),
                        "trace_ms_per_step": round(trace_ms / args.steps / world, 3),

@@ -186,7 +186,7 @@ typedef struct RtRenderParams {
 
 typedef struct RtStats {
   unsigned long long rays_primary, rays_reflect, rays_refract, rays_shadow;
-  unsigned long long nodes_visited, prims_tested;   /* collect_stats only */
+  unsigned long long nodes_visited, prims_tested;   /* collect_stats only: tree nodes visited, triangles tested */
   unsigned long long shade_points;
   double ms_total;           /* host wall time of the call */
   double ms_device;          /* HIP-event time of all kernels of the call */
@@ -199,6 +199,7 @@ typedef struct RtStats {
   unsigned long long shadow_nodes_visited, shadow_prims_tested;  /* shadow rays' share of the two totals */
   int    batches_redone;     /* batches repeated because a recursion level outgrew the grid estimated for it */
   int    _pad2;
+  unsigned long long objects_tested, shadow_objects_tested;      /* collect_stats only: non-mesh objects tested */
 } RtStats;
 
 /* Result of Scene::intersect for one ray (isect, src/scene/ray.h:57-112). */

@@ -82,7 +82,8 @@ class RtStats(C.Structure):
                 ("ms_trace", C.c_double), ("trace_launches", C.c_int), ("batches", C.c_int),
                 ("ms_lights", C.c_double), ("lights_launches", C.c_int), ("_pad", C.c_int),
                 ("shadow_nodes_visited", C.c_ulonglong), ("shadow_prims_tested", C.c_ulonglong),
-                ("batches_redone", C.c_int), ("_pad2", C.c_int)]
+                ("batches_redone", C.c_int), ("_pad2", C.c_int),
+                ("objects_tested", C.c_ulonglong), ("shadow_objects_tested", C.c_ulonglong)]
 
     @property
     def rays_total(self):

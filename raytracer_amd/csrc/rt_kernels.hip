@@ -70,8 +70,8 @@ struct Counters {           // device-resident, one block per recursion level
   unsigned int rayOff;      // pool slot of its first ray
   unsigned int spOff;       // pool index of its first shade point
   unsigned int _pad[2];
-  unsigned long long refl, refr, litsp, nodes, prims;
-  unsigned long long shadowNodes, shadowPrims;   // of the shadow rays (k_lights)
+  unsigned long long refl, refr, litsp, nodes, prims, objs;
+  unsigned long long shadowNodes, shadowPrims, shadowObjs;   // of the shadow rays (k_shadow)
 };
 
 // One counter block per recursion level (and one past the last, which the last
@@ -264,16 +264,18 @@ __device__ __forceinline__ int rayOf(const DevScene& S, const RaySrc& R, int i, 
 }
 
 __device__ __forceinline__ void flushCounters(const TraceCounters& c, Counters* g, bool shadow) {
-  // wave-level sum, one atomic per wavefront
-  unsigned int n = c.nodes, t = c.prims;
+  // wave-level sum, one atomic per counter and wavefront
+  unsigned int n = c.nodes, t = c.prims, o = c.objs;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
     n += __shfl_down(n, off);
     t += __shfl_down(t, off);
+    o += __shfl_down(o, off);
   }
   if ((threadIdx.x & 63) == 0) {
     atomicAdd(shadow ? &g->shadowNodes : &g->nodes, (unsigned long long)n);
     atomicAdd(shadow ? &g->shadowPrims : &g->prims, (unsigned long long)t);
+    if (o) atomicAdd(shadow ? &g->shadowObjs : &g->objs, (unsigned long long)o);
   }
 }
 
@@ -322,7 +324,7 @@ k_trace(DevScene S, RaySrc R, double* hitT, int* hitPrim, Counters* counters) {
   const long long n = counters->n;
   checkCoverage(counters, (long long)gridDim.x * blockDim.x, n);
   const long long i = xcdBlock() * blockDim.x + threadIdx.x;
-  TraceCounters tc{0, 0};
+  TraceCounters tc{0, 0, 0};
   if (i < n) {
     V3 p, d;
     const int type = rayOf(S, R, (int)i, p, d);
@@ -662,7 +664,7 @@ k_shadow(DevScene S, Pool P) {
   checkCoverage(P.counters, (long long)gridDim.x * blockDim.x, nsp);
   const size_t spOff = P.counters->spOff;
   const long long s = xcdBlock() * blockDim.x + threadIdx.x;
-  TraceCounters tc{0, 0};
+  TraceCounters tc{0, 0, 0};
   if (s < nsp) {
     const int li = (int)blockIdx.y;
     if ((unsigned int)P.spMat[spOff + s] & RT_SPM_LIT) {
@@ -976,7 +978,7 @@ k_intersect(DevScene S, int n, const double* rays, const int* types, RtHit* hits
   if (i >= n) return;
   const V3 p(rays + 6 * (size_t)i), d(rays + 6 * (size_t)i + 3);
   const int type = types ? types[i] : RT_RAY_VISIBILITY;
-  TraceCounters tc{0, 0};
+  TraceCounters tc{0, 0, 0};
   double t;
   const int prim = FAST ? traceBvh<false, false>(S, p, d, type, 1.0e308, -1.0, t, tc, (rt_lds_u32*)rtStackLds)
                         : traceKdReference<false>(S, p, d, type, t, tc);
@@ -1158,11 +1160,13 @@ struct RtScene {
   std::vector<unsigned char> eventKind;   // per pair: 0 k_trace, 1 k_lights
   hipEvent_t evStart = nullptr, evStop = nullptr;
   Counters* countersHost = nullptr;   // pinned: the read-back of the counter blocks (kCounterBlocks of them)
-  // Share of a batch's primary samples that each recursion level held in the
-  // batch before ([0]: frame batches, [1]: pixel-list batches): what the next
-  // batch sizes its grids from.
-  struct LevelHistory { int depth = -1, ns = 0; std::vector<double> share; };
-  LevelHistory levelHist[2];
+  // Rays per recursion level of the batches rendered so far, by what the batch
+  // was (pixel range, sampling, depth, frame and shard geometry): a batch that
+  // has been rendered before sizes its grids from these counts.  The scene and
+  // its camera never change under a handle, so they only miss when the caller
+  // changes what the key does not hold (another pixel list of the same length).
+  typedef std::array<long long, 12> BatchKey;
+  std::map<BatchKey, std::vector<unsigned int>> levelHist;
   std::vector<unsigned int> levelN = std::vector<unsigned int>(kCounterBlocks, 0u);   // level-sync batches: rays per level
   int levelSyncMode = 0;              // RT_AMD_LEVEL_SYNC=1: read every level's count back before the next
 
@@ -1402,11 +1406,11 @@ void timedEnd(RtScene* sc, hipStream_t st, int kind) {
 // The whole batch -- every recursion level, the bottom-up pass and the resolve
 // -- is queued without a host round trip: a level's ray and shade-point counts
 // stay on the device (Counters::n / rayOff / spOff, handed on by k_advance) and
-// the grids are sized from estimates, the share of the primary samples that
-// each level held in the batch before (RtScene::levelShare).  One read-back of
-// all counter blocks and ONE stream synchronisation end the batch.  A batch
-// without history (first of a scene, other depth or sampling) reads each
-// level's count back before it sizes the next, as does RT_AMD_LEVEL_SYNC=1.
+// the grids are sized from what each level held when the same batch was
+// rendered before (RtScene::levelHist).  One read-back of all counter blocks
+// and ONE stream synchronisation end the batch.  A batch that is new to the
+// scene handle reads each level's count back before it sizes the next, as does
+// every batch under RT_AMD_LEVEL_SYNC=1.
 int renderBatch(RenderCtx& cx, long long first, int count, long long* slotsUsed, bool forceSync) {
   RtScene* sc = cx.sc;
   const Pool& pool = sc->pool;
@@ -1415,9 +1419,14 @@ int renderBatch(RenderCtx& cx, long long first, int count, long long* slotsUsed,
   const long long nSamples = (long long)count * ns;
   if ((size_t)nSamples > pool.cap) return 1;
   const int nLevels = rp.depth + 1;
-  const int histKey = (cx.fm.pixelList ? 1 : 0);
-  RtScene::LevelHistory& hist = sc->levelHist[histKey];
-  const bool haveHist = hist.depth == rp.depth && hist.ns == ns && (int)hist.share.size() == nLevels;
+  const RtScene::BatchKey key{cx.fm.pixelList ? 1 : 0, first, count, ns, rp.depth, cx.fm.width, cx.fm.height,
+                              cx.fm.tileW, cx.fm.tileH, cx.fm.shardIndex, cx.fm.shardCount, cx.fm.aaN};
+  std::vector<unsigned int> hist;
+  {
+    auto it = sc->levelHist.find(key);
+    if (it != sc->levelHist.end()) hist = it->second;
+  }
+  const bool haveHist = (int)hist.size() == nLevels;
   const bool levelSync = !haveHist || forceSync || sc->levelSyncMode == 1;
   HIP_TRY(hipMemsetAsync(pool.counters, 0, sizeof(Counters) * (size_t)(nLevels + 1), sc->stream));
   k_begin<<<1, 1, 0, sc->stream>>>(pool.counters, (unsigned int)nSamples);
@@ -1445,8 +1454,8 @@ int renderBatch(RenderCtx& cx, long long first, int count, long long* slotsUsed,
         est = (long long)sc->countersHost[0].n;
         if (est == 0) break;
       } else {
-        // a quarter above the share the level had last time, never less than a block
-        est = (long long)(hist.share[level] * 1.25 * (double)nSamples) + 256;
+        // what the level held when this batch was rendered before (and a little more)
+        est = (long long)hist[(size_t)level] + (long long)(hist[(size_t)level] >> 4) + 256;
       }
     }
     levelsRun = level + 1;
@@ -1521,13 +1530,15 @@ int renderBatch(RenderCtx& cx, long long first, int count, long long* slotsUsed,
     if (flags & RT_OVERFLOW_POOL) return 1;
     if (flags) return 2;
   }
-  unsigned long long litTotal = 0, nodes = 0, prims = 0, refl = 0, refr = 0, snodes = 0, sprims = 0;
+  unsigned long long litTotal = 0, nodes = 0, prims = 0, objs = 0, refl = 0, refr = 0, snodes = 0, sprims = 0, sobjs = 0;
   size_t rayEnd = 0, spEnd = 0;
-  hist.share.assign((size_t)nLevels, 0.0);
+  hist.assign((size_t)nLevels, 0u);
   for (int l = 0; l < levelsRun; l++) {
     litTotal += c[l].litsp;
     nodes += c[l].nodes;
     prims += c[l].prims;
+    objs += c[l].objs;
+    sobjs += c[l].shadowObjs;
     snodes += c[l].shadowNodes;
     sprims += c[l].shadowPrims;
     refl += c[l].refl;
@@ -1535,10 +1546,10 @@ int renderBatch(RenderCtx& cx, long long first, int count, long long* slotsUsed,
     cx.stats.shade_points += (unsigned long long)c[l].nsp;
     rayEnd = (size_t)c[l].rayOff + c[l].n;
     spEnd = (size_t)c[l].spOff + c[l].nsp;
-    hist.share[(size_t)l] = (double)c[l].n / (double)nSamples;
+    hist[(size_t)l] = c[l].n;
   }
-  hist.depth = rp.depth;
-  hist.ns = ns;
+  if (sc->levelHist.size() >= 64 && !sc->levelHist.count(key)) sc->levelHist.clear();
+  sc->levelHist[key] = hist;
   // stats: dead (out-of-frame) slots are not rays
   cx.stats.rays_reflect += refl;
   cx.stats.rays_refract += refr;
@@ -1547,6 +1558,8 @@ int renderBatch(RenderCtx& cx, long long first, int count, long long* slotsUsed,
   cx.stats.prims_tested += prims + sprims;
   cx.stats.shadow_nodes_visited += snodes;
   cx.stats.shadow_prims_tested += sprims;
+  cx.stats.objects_tested += objs + sobjs;
+  cx.stats.shadow_objects_tested += sobjs;
   cx.stats.batches++;
   *slotsUsed = (long long)std::max(rayEnd, spEnd);
   return RT_OK;

@@ -144,7 +144,8 @@ struct DevScene {
 #define RT_PRIM_NONE (-1)
 #define RT_PRIM_FACE 0x40000000  // prim = RT_PRIM_FACE | global face index, else object index
 
-struct TraceCounters { uint32_t nodes, prims; };
+// nodes visited, triangles tested, non-mesh objects tested (counted in STATS builds)
+struct TraceCounters { uint32_t nodes, prims, objs; };
 
 // BoundingBox::intersect (src/scene/bbox.h:62-89).  On an early `false` the
 // outputs keep the partial values, which the reference's callers go on to use.
@@ -488,7 +489,7 @@ __device__ int traceKdReference(const DevScene& S, const V3& p, const V3& d, int
       } else {
         double t;
         V3 N;
-        if (STATS) cnt.prims++;
+        if (STATS) cnt.objs++;
         if (objectIntersect<false>(o, p, d, t, N)) {
           if (!haveOne || t < bestT) { haveOne = true; bestT = t; bestPrim = j; }
         }
@@ -555,7 +556,7 @@ __device__ int traceKdReference(const DevScene& S, const V3& p, const V3& d, int
           }
           double t;
           V3 N;
-          if (STATS) cnt.prims++;
+          if (STATS) cnt.objs++;
           if (objectIntersect<false>(o, p, d, t, N)) {
             if (!haveOne || t < bestT) { haveOne = true; bestT = t; bestPrim = oi; }
           }
@@ -712,7 +713,7 @@ __device__ __forceinline__ int bvhScanNaN(const DevScene& S, const V3& p, const 
     if (o.kind == RT_OBJ_TRIMESH) continue;
     double t;
     V3 N;
-    if (STATS) cnt.prims++;
+    if (STATS) cnt.objs++;
     if (objectIntersect<false>(o, p, d, t, N) && (!have || t < bt)) { have = true; bt = t; bp = j; }
   }
   tOut = bt;
@@ -878,7 +879,7 @@ __device__ __forceinline__ bool bvhLeaf(const DevScene& S, const V3& p, const V3
     const int oi = x & 0x3fffffff;
     double t;
     V3 N;
-    if (STATS) cnt.prims++;
+    if (STATS) cnt.objs++;
     if (objectIntersect<false>(S.objects[oi], p, d, t, N)) {
       if (ANYHIT) {
         const V3 Qh = p + (t * d);

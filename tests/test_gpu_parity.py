@@ -355,11 +355,11 @@ def test_one_stream_and_two_streams_give_the_same_frame(built, monkeypatch):
 
 
 def test_level_estimates_and_the_redo_of_an_outgrown_batch(built, monkeypatch):
-    """Frames after a scene's first are queued without reading a level's ray
-    count back (grids sized from the shares the batch before had); the frame
-    must equal the one rendered level by level (RT_AMD_LEVEL_SYNC=1).  A batch
-    whose levels outgrow those estimates is redone: sky pixels first (no
-    secondary rays), then the same number of pixels on the reflecting spheres."""
+    """A batch that a scene handle has rendered before is queued without reading
+    a level's ray count back (grids sized from the counts it had then); the
+    frame must equal the one rendered level by level (RT_AMD_LEVEL_SYNC=1).  A
+    batch whose levels outgrow those sizes is redone: a list of sky pixels
+    first (no secondary rays), then as many pixels on the reflecting spheres."""
     hs = host.HostScene(text=scenes.simple_scene())
     kw = dict(width=128, height=128, depth=3, traversal=abi.RT_TRAVERSE_FAST)
     frames = []

@@ -44,6 +44,9 @@ def main():
     os.makedirs(dst, exist_ok=True)
     shutil.copy(os.path.join(src, "trace", "bench_kernel_stats.csv"), os.path.join(dst, tag + "_kernel_stats.csv"))
     shutil.copy(os.path.join(src, "bench_under_rocprof.json"), os.path.join(dst, tag + "_bench_under_rocprof.json"))
+    for name in ("frame_split_one_stream.md", "bench_one_stream.json"):
+        if os.path.exists(os.path.join(src, name)):
+            shutil.copy(os.path.join(src, name), os.path.join(dst, tag + "_" + name))
 
     # rocprofv3's own stats average every launch of the process, warm-up frame and
     # counter pass included; the timed steps are the last launches of the
@@ -89,8 +92,18 @@ def main():
             100.0 * v["SQ_WAIT_ANY"] / wc, 100.0 * v["SQ_WAIT_INST_ANY"] / wc, 100.0 * v["SQ_ACTIVE_INST_ANY"] / wc))
     open(os.path.join(dst, tag + "_pmc_summary.md"), "w").write("\n".join(lines) + "\n")
     kt = next((traffic[k] for k in traffic if k.startswith("k_trace")), None)
-    out = {"source": "profiles/%s_pmc_summary.md" % tag, "kernels": traffic}
+    import subprocess
+    try:
+        commit = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+        dirty = subprocess.run(["git", "-C", ROOT, "status", "--porcelain", "--", "raytracer_amd/csrc", "bench.py"],
+                               capture_output=True, text=True).stdout.strip()
+        if dirty:
+            commit += "+uncommitted"
+    except Exception:
+        commit = None
+    out = {"source": "profiles/%s_pmc_summary.md" % tag, "commit": commit, "kernels": traffic}
     if kt:
+        out["k_trace_waves_per_simd"] = kt["waves_per_simd"]
         out["k_trace_hbm_bytes_per_launch"] = kt["read_bytes_per_launch"] + kt["write_bytes_per_launch"]
         out["k_trace_valu_busy"] = kt["valu_busy"]
         out["k_trace_lanes_active"] = kt["lanes_active"]
