@@ -226,15 +226,24 @@ struct RaySrc {
   SlotBase first;         // pixel slot of sample 0 of the batch
 };
 
+// A ray of a level; type < 0: no ray in this slot.  (Handed around by value:
+// with output references the compiler merges the stores of the two sources of
+// a ray behind a selected address, and the ray then lives in scratch memory.)
+struct RayPD {
+  V3 p, d;
+  int type;
+};
+
 // Camera::rayThrough (camera.cpp:20-31) at the coordinates of tracePixel /
-// tracePixelAntiAlias (RayTracer.cpp:51-52,84-92) for sample i of the batch.
-// Returns the ray type, -1 for a sample of a pixel slot outside the frame.
-__device__ __forceinline__ int primaryRay(const DevScene& S, const FrameMap& fm, const SlotBase& first, int i,
-                                          V3& p, V3& dir) {
+// tracePixelAntiAlias (RayTracer.cpp:51-52,84-92) for sample i of the batch;
+// type -1 for a sample of a pixel slot outside the frame.
+__device__ __forceinline__ RayPD primaryRay(const DevScene& S, const FrameMap& fm, const SlotBase& first, int i) {
+  RayPD r;
+  r.type = -1;
   const unsigned int rel = fastDiv((unsigned int)i, fm.dNs);
   const int k = (int)((unsigned int)i - rel * fm.dNs.d);
   int px, py, tk, lx, ly;
-  if (!slotToPixel(fm, first, rel, px, py, tk, lx, ly)) return -1;
+  if (!slotToPixel(fm, first, rel, px, py, tk, lx, ly)) return r;
   double x = double(px) / double(fm.width);
   double y = double(py) / double(fm.height);
   if (fm.aaN > 0) {
@@ -247,20 +256,28 @@ __device__ __forceinline__ int primaryRay(const DevScene& S, const FrameMap& fm,
   }
   x -= 0.5;
   y -= 0.5;
-  dir = normalized(V3(S.look) + x * V3(S.u) + y * V3(S.v));
-  p = V3(S.eye);
-  return RT_RAY_VISIBILITY;
+  r.d = normalized(V3(S.look) + x * V3(S.u) + y * V3(S.v));
+  r.p = V3(S.eye);
+  r.type = RT_RAY_VISIBILITY;
+  return r;
 }
 
-// Ray i of the level; returns its type (< 0: no ray in this slot).
-__device__ __forceinline__ int rayOf(const DevScene& S, const RaySrc& R, int i, V3& p, V3& d) {
-  if (R.primary) return primaryRay(S, R.fm, R.first, i, p, d);
-  const int type = R.type[i];
-  if (type >= 0) {
-    p = loadV3(R.p, R.stride, i);
-    d = loadV3(R.d, R.stride, i);
+// Ray i of the level.
+__device__ __forceinline__ RayPD rayAt(const DevScene& S, const RaySrc& R, int i) {
+  if (R.primary) return primaryRay(S, R.fm, R.first, i);
+  RayPD r;
+  r.type = R.type[i];
+  if (r.type >= 0) {
+    r.p = loadV3(R.p, R.stride, i);
+    r.d = loadV3(R.d, R.stride, i);
   }
-  return type;
+  return r;
+}
+__device__ __forceinline__ int rayOf(const DevScene& S, const RaySrc& R, int i, V3& p, V3& d) {
+  const RayPD r = rayAt(S, R, i);
+  p = r.p;
+  d = r.d;
+  return r.type;
 }
 
 __device__ __forceinline__ void flushCounters(const TraceCounters& c, Counters* g, bool shadow) {
