@@ -749,7 +749,8 @@ __device__ __forceinline__ void shadePoint(const DevScene& S, const Pool& P, int
     // outside a spot cone) adds +0 to every component when the Phong factors are
     // finite: skip their sqrt / pow.  A NaN shade point (the hit of a NaN ray)
     // makes the factors NaN, and the reference's 0 * NaN then poisons the colour.
-    if (iszero(lightIntensity) && !anynan(Q) && !anynan(N) && !anynan(L)) continue;
+    // So does a negative shininess: pow(0, negative) is infinite and 0 * inf is NaN.
+    if (iszero(lightIntensity) && !anynan(Q) && !anynan(N) && !anynan(L) && !(hasKs && shin < 0.0)) continue;
     // std::max(x, 0.0) of material.cpp:61,72 is (x < 0.0) ? 0.0 : x -- it hands a NaN on
     if (hasKd) {
       const double c = dot(N, L);
@@ -1057,6 +1058,68 @@ k_edge_mask(const unsigned char* rgb, int w, int h, int cutOff, unsigned char* m
   mask[i] = (sum > cutOff) ? 255 : 0;
 }
 
+// ---- flagged pixels of an edge mask, as an (x, y) list in row-major order ----
+// GraphicalUI::doAntiAliasing walks the mask row by row (ui/GraphicalUI.cpp:
+// 405-425); the list keeps that order: a block counts the flagged pixels of its
+// kBlock consecutive pixels, one workgroup turns the counts into offsets (and
+// tells the host the total through mapped host memory), a block writes its
+// pixels behind its offset in pixel order.
+__global__ void __launch_bounds__(kBlock)
+k_flag_count(const unsigned char* mask, long long n, unsigned int* blockCount) {
+  __shared__ unsigned int waveCount[kWaves];
+  const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+  const unsigned long long m = __ballot(i < n && mask[i] == 255);
+  if ((threadIdx.x & 63) == 0) waveCount[threadIdx.x >> 6] = (unsigned int)__popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned int c = 0;
+    for (int k = 0; k < kWaves; k++) c += waveCount[k];
+    blockCount[blockIdx.x] = c;
+  }
+}
+
+// Exclusive scan of nBlocks counts in place by ONE workgroup of 1024 threads
+// (a 4K frame has 32 400 of them); *totalHost is device-visible host memory.
+__global__ void __launch_bounds__(1024)
+k_flag_scan(unsigned int* blockCount, int nBlocks, unsigned int* totalHost) {
+  __shared__ unsigned int part[1024];
+  const int per = (nBlocks + 1023) / 1024;
+  const int lo = min(nBlocks, (int)threadIdx.x * per), hi = min(nBlocks, lo + per);
+  unsigned int mine = 0;
+  for (int k = lo; k < hi; k++) mine += blockCount[k];
+  part[threadIdx.x] = mine;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {   // inclusive scan of the 1024 partial sums
+    const unsigned int o = threadIdx.x >= (unsigned int)off ? part[threadIdx.x - off] : 0u;
+    __syncthreads();
+    part[threadIdx.x] += o;
+    __syncthreads();
+  }
+  unsigned int run = part[threadIdx.x] - mine;
+  for (int k = lo; k < hi; k++) {
+    const unsigned int c = blockCount[k];
+    blockCount[k] = run;
+    run += c;
+  }
+  if (threadIdx.x == 1023) *totalHost = part[1023];
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_flag_write(const unsigned char* mask, int w, long long n, const unsigned int* blockOffset, int* xy) {
+  __shared__ unsigned int waveCount[kWaves];
+  const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+  const bool flag = i < n && mask[i] == 255;
+  const unsigned long long m = __ballot(flag);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) waveCount[wave] = (unsigned int)__popcll(m);
+  __syncthreads();
+  if (!flag) return;
+  unsigned int slot = blockOffset[blockIdx.x] + (unsigned int)__popcll(m & ((1ull << lane) - 1ull));
+  for (int k = 0; k < wave; k++) slot += waveCount[k];
+  xy[2 * (size_t)slot] = (int)(i % w);
+  xy[2 * (size_t)slot + 1] = (int)(i / w);
+}
+
 }  // namespace
 
 // ================================================================ host side
@@ -1249,14 +1312,23 @@ int ensurePool(RtScene* sc, size_t cap) {
   if (sc->pool.cap >= cap && sc->poolLights >= nl) return RT_OK;
   sc->freePool();
   Pool& P = sc->pool;
+  bool outOfMemory = false;
   auto A = [&](size_t bytes, void** out) -> hipError_t {
     hipError_t e = hipMalloc(out, bytes);
     if (e == hipSuccess) sc->poolAllocs.push_back(*out);
+    else if (e == hipErrorOutOfMemory) outOfMemory = true;
     return e;
   };
   // per-point material arrays only where some mesh interpolates materials
   const size_t icap = sc->dev.interp_materials ? cap : 1;
-#define POOL_ALLOC(field, type, count) HIP_TRY(A(sizeof(type) * (count), (void**)&(field)))
+#define POOL_ALLOC(field, type, count)                                                          \
+  do {                                                                                          \
+    if (A(sizeof(type) * (count), (void**)&(field)) != hipSuccess) {                            \
+      (void)hipGetLastError();                                                                  \
+      sc->freePool();                                                                           \
+      return fail(outOfMemory ? RT_ERR_NOMEM : RT_ERR_DEVICE, "cannot allocate the ray pool");  \
+    }                                                                                           \
+  } while (0)
   for (int b = 0; b < 2; b++) {
     POOL_ALLOC(P.rayP[b], double, 3 * cap);
     POOL_ALLOC(P.rayD[b], double, 3 * cap);
@@ -2192,35 +2264,44 @@ int rt_render(RtScene* sc, const RtRenderParams* rp, unsigned char* rgb8_out, in
   if (rc != RT_OK) return rc;
   cx.stats.rays_primary = (unsigned long long)TL.pixels * fm.ns;
 
-  std::vector<int> flagged;
-  DevBuf maskBuf, listBuf;
+  DevBuf maskBuf, countBuf, listBuf;
   if (rp->aa_mode == RT_AA_ADAPTIVE) {
     // GraphicalUI::doAntiAliasing (ui/GraphicalUI.cpp:377-435): edge mask on the
     // finished base image, then tracePixelAntiAlias on the flagged pixels only.
-    HIP_TRY(maskBuf.alloc((size_t)w * h));
+    // Mask, count and list stay on the device; the host learns one number, how
+    // many pixels were flagged (through mapped host memory, no copy), because
+    // the second pass is sized by it.
+    const long long npx = (long long)w * h;
+    const int nBlocks = gridFor(npx);
+    HIP_TRY(maskBuf.alloc((size_t)npx));
+    HIP_TRY(countBuf.alloc((size_t)nBlocks * sizeof(unsigned int)));
     unsigned char* maskDev = maskBuf.as<unsigned char>();
-    k_edge_mask<<<gridFor((long long)w * h), kBlock, 0, sc->stream>>>(sc->frameRgb, w, h, rp->aa_threshold, maskDev);
-    std::vector<unsigned char> mask((size_t)w * h);
-    HIP_TRY(hipMemcpyAsync(mask.data(), maskDev, mask.size(), hipMemcpyDeviceToHost, sc->stream));
+    unsigned int* countDev = countBuf.as<unsigned int>();
+    unsigned int* totalHost = reinterpret_cast<unsigned int*>(sc->countersHost);   // pinned, device-visible
+    *totalHost = 0;
+    k_edge_mask<<<nBlocks, kBlock, 0, sc->stream>>>(sc->frameRgb, w, h, rp->aa_threshold, maskDev);
+    k_flag_count<<<nBlocks, kBlock, 0, sc->stream>>>(maskDev, npx, countDev);
+    k_flag_scan<<<1, 1024, 0, sc->stream>>>(countDev, nBlocks, totalHost);
+    HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(sc->stream));
-    for (int y = 0; y < h; y++)
-      for (int x = 0; x < w; x++)
-        if (mask[(size_t)y * w + x] == 255) { flagged.push_back(x); flagged.push_back(y); }
-    if (!flagged.empty()) {
-      HIP_TRY(listBuf.alloc(flagged.size() * sizeof(int)));
+    const long long nFlag = (long long)*totalHost;
+    if (nFlag > 0) {
+      HIP_TRY(listBuf.alloc((size_t)nFlag * 2 * sizeof(int)));
       int* listDev = listBuf.as<int>();
-      HIP_TRY(hipMemcpyAsync(listDev, flagged.data(), flagged.size() * sizeof(int), hipMemcpyHostToDevice, sc->stream));
+      k_flag_write<<<nBlocks, kBlock, 0, sc->stream>>>(maskDev, w, npx, countDev, listDev);
       fm.pixelList = listDev;
       fm.ns = nsFull;
       fm.aaN = rp->aa_samples;
       setDivisors(fm);
       int* keepHit = cx.hitDev;
       cx.hitDev = nullptr;  // the base pass already recorded the primary hits
-      const long long nFlag = (long long)flagged.size() / 2;
       rc = renderRange(cx, 0, nFlag);
       cx.hitDev = keepHit;
       cx.stats.rays_primary += (unsigned long long)nFlag * nsFull;
-      if (rc != RT_OK) return rc;
+      if (rc != RT_OK) {
+        hipStreamSynchronize(sc->stream);   // the buffers go away with this call
+        return rc;
+      }
     }
   }
   HIP_TRY(hipEventRecord(sc->evStop, sc->stream));

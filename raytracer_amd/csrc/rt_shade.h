@@ -155,119 +155,127 @@ __device__ __forceinline__ V3 cubePixel(const DevScene& S, int face, int x, int 
   return V3(double(data[0]) / 255.0, double(data[1]) / 255.0, double(data[2]) / 255.0);
 }
 
-// CubeMap::getColor (cubeMap.cpp:6-208).  A NaN direction (refraction past the
-// critical angle, RayTracer.cpp:193-199) makes the reference skip every filter
-// tap and return 0/0, reproduced here as a NaN colour.
+// ---- CubeMap::getColor (cubeMap.cpp:6-208) -----------------------------------
+// What the reference spells as nested branches is a table: for each of the six
+// faces a direction can look at (axis, sign), the map slot of that face, and for
+// a filter tap that leaves it across its bottom / top / left / right edge the
+// slot of the neighbouring map and where the tap lands in it.  A landing
+// coordinate is always  base + sign * variable  with base one of
+// 0, -1, W, W-1, H, H-1 and the variable one of the tap's in-face indices
+// (xi, yi) or its loop offsets (ii, jj) -- the reference uses the offsets, not
+// the indices, along the crossed edge (cubeMap.cpp:125-205).
+//
+// Landing code: bits 0-2 base (bit 0: minus one; bits 1-2: 0 / W / H),
+// bits 3-5 variable (0 none, 1 xi, 2 yi, 3 ii, 4 jj), bit 6 negative.
+#define RT_CL(base, var, neg) ((base) | ((var) << 3) | ((neg) << 6))
+#define RT_CL_0 0
+#define RT_CL_M1 1
+#define RT_CL_W 2
+#define RT_CL_W1 3
+#define RT_CL_H 4
+#define RT_CL_H1 5
+#define RT_CL_XI 1
+#define RT_CL_YI 2
+#define RT_CL_II 3
+#define RT_CL_JJ 4
+struct CubeEdge { unsigned char slot, x, y; };
+struct CubeFace { unsigned char front; CubeEdge edge[4]; };   // edge: 0 bottom (yi < 0), 1 top, 2 left (xi < 0), 3 right
+#define RT_CL_SAME_X RT_CL(RT_CL_0, RT_CL_XI, 0)
+#define RT_CL_SAME_Y RT_CL(RT_CL_0, RT_CL_YI, 0)
+__constant__ CubeFace kCubeFaces[6] = {
+    // looking down +x: slot 0; below slot 3, above slot 2, left slot 4, right slot 5
+    {0, {{3, RT_CL(RT_CL_W, RT_CL_JJ, 0), RT_CL(RT_CL_H1, RT_CL_XI, 1)}, {2, RT_CL(RT_CL_W, RT_CL_JJ, 1), RT_CL_SAME_X},
+         {4, RT_CL(RT_CL_W, RT_CL_II, 0), RT_CL_SAME_Y}, {5, RT_CL(RT_CL_M1, RT_CL_II, 0), RT_CL_SAME_Y}}},
+    // -x: slot 1
+    {1, {{3, RT_CL(RT_CL_M1, RT_CL_JJ, 1), RT_CL_SAME_X}, {2, RT_CL(RT_CL_M1, RT_CL_JJ, 0), RT_CL(RT_CL_H1, RT_CL_XI, 1)},
+         {5, RT_CL(RT_CL_W, RT_CL_II, 0), RT_CL_SAME_Y}, {4, RT_CL(RT_CL_M1, RT_CL_II, 0), RT_CL_SAME_Y}}},
+    // +y: slot 2; below slot 4, above slot 5, left slot 1, right slot 0
+    {2, {{4, RT_CL_SAME_X, RT_CL(RT_CL_H, RT_CL_JJ, 0)}, {5, RT_CL(RT_CL_W1, RT_CL_XI, 1), RT_CL(RT_CL_H, RT_CL_JJ, 1)},
+         {1, RT_CL(RT_CL_W1, RT_CL_YI, 1), RT_CL(RT_CL_H, RT_CL_II, 0)}, {0, RT_CL_SAME_Y, RT_CL(RT_CL_H, RT_CL_II, 1)}}},
+    // -y: slot 3; below slot 5, above slot 4
+    {3, {{5, RT_CL(RT_CL_W1, RT_CL_XI, 1), RT_CL(RT_CL_M1, RT_CL_JJ, 1)}, {4, RT_CL_SAME_X, RT_CL(RT_CL_M1, RT_CL_JJ, 0)},
+         {1, RT_CL_SAME_Y, RT_CL(RT_CL_M1, RT_CL_II, 1)}, {0, RT_CL(RT_CL_W1, RT_CL_YI, 1), RT_CL(RT_CL_M1, RT_CL_II, 0)}}},
+    // +z reads slot 5 (the reference's "Zneg" slot, cubeMap.cpp:32-41,63-72); left slot 0, right slot 1
+    {5, {{3, RT_CL(RT_CL_W1, RT_CL_XI, 1), RT_CL(RT_CL_M1, RT_CL_JJ, 1)}, {2, RT_CL(RT_CL_W1, RT_CL_XI, 1), RT_CL(RT_CL_H, RT_CL_JJ, 1)},
+         {0, RT_CL(RT_CL_W, RT_CL_II, 0), RT_CL_SAME_Y}, {1, RT_CL(RT_CL_M1, RT_CL_II, 0), RT_CL_SAME_Y}}},
+    // -z reads slot 4; left slot 1, right slot 0
+    {4, {{3, RT_CL_SAME_X, RT_CL(RT_CL_H, RT_CL_JJ, 0)}, {2, RT_CL_SAME_X, RT_CL(RT_CL_M1, RT_CL_JJ, 0)},
+         {1, RT_CL(RT_CL_W, RT_CL_II, 0), RT_CL_SAME_Y}, {0, RT_CL(RT_CL_M1, RT_CL_II, 0), RT_CL_SAME_Y}}},
+};
+
+__device__ __forceinline__ int cubeLanding(int code, int W, int H, int xi, int yi, int ii, int jj) {
+  const int span = (code >> 1) & 3;
+  const int base = (span == 1 ? W : (span == 2 ? H : 0)) - (code & 1);
+  const int which = (code >> 3) & 7;
+  const int var = which == 1 ? xi : (which == 2 ? yi : (which == 3 ? ii : (which == 4 ? jj : 0)));
+  return (code & 64) ? base - var : base + var;
+}
+
+// A NaN direction (refraction past the critical angle, RayTracer.cpp:193-199)
+// makes the reference skip every filter tap and return 0/0, reproduced here as
+// a NaN colour.
 __device__ V3 cubeColor(const DevScene& S, const V3& dir, int filterwidth) {
   if (anynan(dir)) {
     const double q = __longlong_as_double(0x7ff8000000000000LL);
     return V3(q, q, q);
   }
-  int axis, front, left = 0, right = 0, top = 0, bottom = 0;
+  // the face: the axis with the strictly largest magnitude, z on ties (cubeMap.cpp:12-73)
+  const double ax = fabs(dir.x), ay = fabs(dir.y), az = fabs(dir.z);
+  const int axis = (ax > ay) ? ((ax > az) ? 0 : 2) : ((ay > az) ? 1 : 2);
+  const double major = axis == 0 ? dir.x : (axis == 1 ? dir.y : dir.z);
+  const bool pos = major > 0.0;
+  const CubeFace& F = kCubeFaces[2 * axis + (pos ? 0 : 1)];
+  // face coordinates (cubeMap.cpp:75-92): one quotient as it is, the other negated on the negative side
   double u, v;
-  if (fabs(dir.x) > fabs(dir.y)) {
-    if (fabs(dir.x) > fabs(dir.z)) {
-      axis = 0; bottom = 3; top = 2;
-      if (dir.x > 0.0) { front = 0; left = 4; right = 5; } else { front = 1; left = 5; right = 4; }
-    } else {
-      axis = 2; bottom = 3; top = 2;
-      if (dir.z > 0.0) { front = 5; left = 0; right = 1; } else { front = 4; left = 1; right = 0; }
-    }
-  } else {
-    if (fabs(dir.y) > fabs(dir.z)) {
-      axis = 1; left = 1; right = 0;
-      if (dir.y > 0.0) { front = 2; bottom = 4; top = 5; } else { front = 3; bottom = 5; top = 4; }
-    } else {
-      axis = 2; bottom = 3; top = 2;
-      if (dir.z > 0.0) { front = 5; left = 0; right = 1; } else { front = 4; left = 1; right = 0; }
-    }
-  }
-  const bool pos = (axis == 0) ? (dir.x > 0) : ((axis == 1) ? (dir.y > 0) : (dir.z > 0));
   if (axis == 0) {
     u = dir.z / dir.x;
-    v = (dir.x > 0.0) ? dir.y / dir.x : -dir.y / dir.x;
+    v = pos ? dir.y / dir.x : -dir.y / dir.x;
   } else if (axis == 1) {
-    u = (dir.y > 0.0) ? dir.x / dir.y : -dir.x / dir.y;
+    u = pos ? dir.x / dir.y : -dir.x / dir.y;
     v = dir.z / dir.y;
   } else {
     u = -dir.x / dir.z;
-    v = (dir.z > 0.0) ? dir.y / dir.z : -dir.y / dir.z;
+    v = pos ? dir.y / dir.z : -dir.y / dir.z;
   }
   u = (u + 1.0) / 2.0;
   v = (v + 1.0) / 2.0;
-  const int fw = (filterwidth + 1) / 2 - 1;
-  const int rm = filterwidth - fw;
-  const int width = S.cube_w, height = S.cube_h;
-  const double delu = 1.0 / width, delv = 1.0 / height;
-  const int x = (int)floor(0.5 + u * (width - 1));
-  const int y = (int)floor(0.5 + v * (height - 1));
-  const double startu = delu * (x - fw), startv = delv * (y - fw);
-  double nextu = startu, nextv = startv;
-  const double xslope = 1.0 / (((double)filterwidth + 1) / 2.0 * delu);
-  const double yslope = 1.0 / (((double)filterwidth + 1) / 2.0 * delv);
-  double correct = 0.0;
-  V3 thePixel(0.0, 0.0, 0.0);
-  for (int jj = -fw; jj < rm; jj++) {
-    for (int ii = -fw; ii < rm; ii++) {
-      int xindex = x + ii, yindex = y + jj;
-      if (xindex < 0 && yindex < 0) continue;
-      if (xindex >= width && yindex >= height) continue;
-      if (xindex >= width && yindex < 0) continue;
-      if (xindex < 0 && yindex >= height) continue;
-      int theMap = front;
-      if (yindex < 0) {
-        theMap = bottom;
-        if (axis == 0) {
-          if (pos) { yindex = height - 1 - xindex; xindex = width + jj; }
-          else { yindex = xindex; xindex = -1 - jj; }
-        } else if (axis == 1) {
-          if (pos) yindex = height + jj;
-          else { yindex = -1 - jj; xindex = width - 1 - xindex; }
-        } else {
-          if (pos) { yindex = -1 - jj; xindex = width - 1 - xindex; }
-          else yindex = height + jj;
-        }
-      } else if (yindex >= height) {
-        theMap = top;
-        if (axis == 0) {
-          if (pos) { yindex = xindex; xindex = width - jj; }
-          else { yindex = height - 1 - xindex; xindex = jj - 1; }
-        } else if (axis == 1) {
-          if (pos) { yindex = height - jj; xindex = width - 1 - xindex; }
-          else yindex = jj - 1;
-        } else {
-          if (pos) { yindex = height - jj; xindex = width - 1 - xindex; }
-          else yindex = jj - 1;
-        }
-      } else if (xindex < 0) {
-        theMap = left;
-        if (axis == 0 || axis == 2) xindex = width + ii;
-        else {
-          if (pos) { xindex = width - 1 - yindex; yindex = height + ii; }
-          else { xindex = yindex; yindex = -1 - ii; }
-        }
-      } else if (xindex >= width) {
-        theMap = right;
-        if (axis == 0 || axis == 2) xindex = ii - 1;
-        else {
-          if (pos) { xindex = yindex; yindex = height - ii; }
-          else { xindex = width - 1 - yindex; yindex = ii - 1; }
-        }
+  const int W = S.cube_w, H = S.cube_h;
+  const int before = (filterwidth + 1) / 2 - 1, after = filterwidth - before;   // taps -before .. after-1
+  const double texelU = 1.0 / W, texelV = 1.0 / H;
+  const int x = (int)floor(0.5 + u * (W - 1));
+  const int y = (int)floor(0.5 + v * (H - 1));
+  const double firstU = texelU * (x - before), firstV = texelV * (y - before);
+  const double slopeU = 1.0 / (((double)filterwidth + 1) / 2.0 * texelU);
+  const double slopeV = 1.0 / (((double)filterwidth + 1) / 2.0 * texelV);
+  double total = 0.0;
+  V3 sum(0.0, 0.0, 0.0);
+  double tapV = firstV;
+  for (int jj = -before; jj < after; jj++) {
+    double tapU = firstU;
+    for (int ii = -before; ii < after; ii++) {
+      const int xi = x + ii, yi = y + jj;
+      const bool below = yi < 0, above = yi >= H, leftOf = xi < 0, rightOf = xi >= W;
+      if ((below || above) && (leftOf || rightOf)) continue;   // a corner belongs to no face (cubeMap.cpp:117-120)
+      int slot = F.front, tx = xi, ty = yi;
+      if (below || above || leftOf || rightOf) {
+        const CubeEdge e = F.edge[below ? 0 : (above ? 1 : (leftOf ? 2 : 3))];
+        slot = e.slot;
+        tx = cubeLanding(e.x, W, H, xi, yi, ii, jj);
+        ty = cubeLanding(e.y, W, H, xi, yi, ii, jj);
       }
       // the reference indexes the texel array unguarded below zero; clamp so a
-      // remapped index can never leave the face
-      if (xindex < 0) xindex = 0;
-      if (yindex < 0) yindex = 0;
-      const double du = u - nextu, dv = v - nextv;
-      const double weight = (1.0 - fabs(du * xslope)) * (1.0 - fabs(dv * yslope));
-      nextu += delu;
-      correct += weight;
-      thePixel = thePixel + cubePixel(S, theMap, xindex, yindex) * weight;
+      // landing coordinate can never leave the face
+      if (tx < 0) tx = 0;
+      if (ty < 0) ty = 0;
+      const double du = u - tapU, dv = v - tapV;
+      const double weight = (1.0 - fabs(du * slopeU)) * (1.0 - fabs(dv * slopeV));   // tent
+      tapU += texelU;
+      total += weight;
+      sum = sum + cubePixel(S, slot, tx, ty) * weight;
     }
-    nextu = startu;
-    nextv += delv;
+    tapV += texelV;
   }
-  return V3(thePixel.x / correct, thePixel.y / correct, thePixel.z / correct);
+  return V3(sum.x / total, sum.y / total, sum.z / total);
 }
 
 // Light::getDirection followed by the extra normalize in Material::shade

@@ -189,28 +189,43 @@ __device__ __forceinline__ bool sphereLocal(const V3& p, const V3& d, double& t,
   return true;
 }
 
-// Box.cpp:11-79
-__device__ __forceinline__ bool boxLocal(const V3& p, const V3& d, double& t, V3& N) {
-  double bestT = 1e100;
-  int bestIndex = -1;
-#pragma unroll
-  for (int it = 0; it < 6; it++) {
-    const int mod0 = it % 3, mod1 = (it + 1) % 3, mod2 = (it + 2) % 3;
-    if (d.get(mod0) == 0) continue;
-    double tt = ((it / 3) - 0.5 - p.get(mod0)) / d.get(mod0);
-    if (tt < RT_EPS || tt > bestT) continue;
-    double x = p.get(mod1) + tt * d.get(mod1);
-    double y = p.get(mod2) + tt * d.get(mod2);
-    if (x <= 0.5 && x >= -0.5 && y <= 0.5 && y >= -0.5) {
-      if (bestT > tt) { bestT = tt; bestIndex = it; }
-    }
+// Box.cpp:11-79: the unit cube as three pairs of planes.  One plane: the ray
+// parameter where it meets the plane `at` of axis A, kept when it lies in front
+// of the ray, is not beyond the best so far and lands inside the face.  The
+// reference visits the planes in the order -x -y -z +x +y +z and replaces the
+// best only by a strictly smaller parameter; boxLocal keeps that order.
+template <int A>
+__device__ __forceinline__ double axisOf(const V3& v) { return A == 0 ? v.x : (A == 1 ? v.y : v.z); }
+
+template <int A>
+__device__ __forceinline__ void boxPlane(const V3& p, const V3& d, double at, int face, double& nearest, int& nearestFace) {
+  const double along = axisOf<A>(d);
+  if (along == 0) return;
+  const double tt = (at - axisOf<A>(p)) / along;
+  if (tt < RT_EPS || tt > nearest) return;
+  const double e1 = axisOf<(A + 1) % 3>(p) + tt * axisOf<(A + 1) % 3>(d);
+  const double e2 = axisOf<(A + 2) % 3>(p) + tt * axisOf<(A + 2) % 3>(d);
+  if (e1 <= 0.5 && e1 >= -0.5 && e2 <= 0.5 && e2 >= -0.5 && nearest > tt) {
+    nearest = tt;
+    nearestFace = face;
   }
-  if (bestIndex < 0) return false;
-  t = bestT;
-  if (bestIndex < 3)
-    N = V3(-double(bestIndex == 0), -double(bestIndex == 1), -double(bestIndex == 2));
-  else
-    N = V3(double(bestIndex == 3), double(bestIndex == 4), double(bestIndex == 5));
+}
+
+__device__ __forceinline__ bool boxLocal(const V3& p, const V3& d, double& t, V3& N) {
+  double nearest = 1e100;
+  int face = -1;
+  boxPlane<0>(p, d, -0.5, 0, nearest, face);
+  boxPlane<1>(p, d, -0.5, 1, nearest, face);
+  boxPlane<2>(p, d, -0.5, 2, nearest, face);
+  boxPlane<0>(p, d, 0.5, 3, nearest, face);
+  boxPlane<1>(p, d, 0.5, 4, nearest, face);
+  boxPlane<2>(p, d, 0.5, 5, nearest, face);
+  if (face < 0) return false;
+  t = nearest;
+  // outward normal of the face: -axis for the three lower planes, +axis for the upper ones
+  const double s = face < 3 ? -1.0 : 1.0;
+  const int axis = face < 3 ? face : face - 3;
+  N = V3(s * double(axis == 0), s * double(axis == 1), s * double(axis == 2));
   return true;
 }
 
@@ -862,6 +877,20 @@ __device__ __forceinline__ void bvhSort4(float tn[4], int kid[4]) {
 #undef RT_CSWAP
 }
 
+// Which of two primitives at exactly the same distance the reference's scan over
+// Scene::objects keeps: the one it meets first -- the earlier object, and within
+// a mesh the earlier face (strict < at scene.cpp:148 and in
+// Trimesh::intersectLocal, trimesh.cpp:62-82).  The BVH meets primitives in its
+// own order, so ties are settled by this instead of by arrival.
+__device__ __forceinline__ bool sceneOrderBefore(const DevScene& S, int prim, int other) {
+  if (other == RT_PRIM_NONE) return true;
+  const int fa = prim & ~RT_PRIM_FACE, fb = other & ~RT_PRIM_FACE;
+  const int oa = (prim & RT_PRIM_FACE) ? S.tris[fa].owner : prim;
+  const int ob = (other & RT_PRIM_FACE) ? S.tris[fb].owner : other;
+  if (oa != ob) return oa < ob;
+  return fa < fb;   // two faces of one mesh
+}
+
 // The primitives of leaf reference `ref` (< 0).  Closest hit: updates the best
 // hit.  Occlusion: returns true at the first hit that satisfies the reference's
 // test |(p + t d) - p|^2 < occDist2 (occDist2 < 0: any hit), with tHit set.
@@ -884,7 +913,7 @@ __device__ __forceinline__ bool bvhLeaf(const DevScene& S, const V3& p, const V3
       if (ANYHIT) {
         const V3 Qh = p + (t * d);
         if (occDist2 < 0.0 || length2(Qh - p) < occDist2) { tHit = t; return true; }
-      } else if (!haveOne || t < bestT) {
+      } else if (!haveOne || t < bestT || (t == bestT && sceneOrderBefore(S, oi, bestPrim))) {
         haveOne = true; bestT = t; bestPrim = oi;
         bestTf = roundUpF(bestT);
       }
@@ -924,7 +953,7 @@ __device__ __forceinline__ bool bvhLeaf(const DevScene& S, const V3& p, const V3
       if (ANYHIT) {
         const V3 Qh = p + (tw * d);
         if (occDist2 < 0.0 || length2(Qh - p) < occDist2) { tHit = tw; return true; }
-      } else if (!haveOne || tw < bestT) {
+      } else if (!haveOne || tw < bestT || (tw == bestT && sceneOrderBefore(S, RT_PRIM_FACE | face, bestPrim))) {
         haveOne = true; bestT = tw; bestPrim = RT_PRIM_FACE | face;
         bestTf = roundUpF(bestT);
       }

@@ -93,6 +93,40 @@ def test_lights_inside_a_closed_opaque_room(built, trav, kd):
     assert st.rays_shadow == rs.rays_shadow and st.shade_points == rs.shade_points
 
 
+def test_coincident_surfaces_keep_the_first_in_scene_order(built):
+    """Two primitives hit at exactly the same distance: the reference's scan keeps
+    the one that comes first in the scene (strict < at scene.cpp:148, first face
+    first inside a mesh, trimesh.cpp:62-82).  The BVH meets them in its own order
+    and must settle the tie the same way: the same quad twice as two meshes with
+    different materials, a mesh that lists a face twice, two spheres in one place."""
+    s = scenes.HEADER
+    s += scenes.camera((0.0371, 1.0137, -6.0213), (0.0, -0.05, 1.0), aspect=1.0, fov=40.0)
+    s += scenes.ambient_light((0.3, 0.3, 0.3))
+    s += scenes.point_light((2.1237, 4.3411, -5.2173))
+    quad_v = np.array([[-2.5013, 0.0011, 1.0], [-0.5017, 0.0013, 1.0], [-2.5011, 2.0017, 1.0], [-0.5019, 2.0011, 1.0]])
+    quad_f = np.array([[0, 2, 1], [1, 2, 3]])
+    red = scenes.material(diffuse=(0.8, 0.1, 0.1), ambient=(0.8, 0.1, 0.1))
+    blue = scenes.material(diffuse=(0.1, 0.1, 0.8), ambient=(0.1, 0.1, 0.8))
+    green = scenes.material(diffuse=(0.1, 0.7, 0.1), ambient=(0.1, 0.7, 0.1), reflective=(0.3, 0.3, 0.3))
+    s += scenes.trimesh(quad_v, quad_f, red, gennormals=False)
+    s += scenes.trimesh(quad_v, quad_f, blue, gennormals=False)
+    dup_v = quad_v + np.array([3.0, 0.0, 0.0])
+    dup_f = np.array([[0, 2, 1], [1, 2, 3], [0, 2, 1], [1, 2, 3]])
+    s += scenes.trimesh(dup_v, dup_f, green, gennormals=False)
+    s += scenes.translate((0.0113, 3.2, 2.0117), scenes.prim("sphere", red))
+    s += scenes.translate((0.0113, 3.2, 2.0117), scenes.prim("sphere", blue))
+    lin = host.HostScene(text=s, kd_tree=False)
+    hs = host.HostScene(text=s)
+    ds = device.DeviceScene(hs.desc_ptr)
+    p, _ = host.render_params(96, 96, depth=2, traversal=abi.RT_TRAVERSE_FAST)
+    rgb, hits, st = ds.render(p)
+    ds.close()
+    rr, rh, rs = loader.render(lin.desc_ptr, p, threads=4)
+    assert len(np.unique(rh)) >= 5      # both quads' faces, the duplicated mesh and the first sphere are seen
+    common.assert_parity(rgb, hits, rr, rh, what="coincident surfaces")
+    assert st.rays_total == rs.rays_total
+
+
 def test_largest_sample_grid(built):
     hs = host.HostScene(text=scenes.simple_scene())
     jit = host.jitter_table(7, 8)
