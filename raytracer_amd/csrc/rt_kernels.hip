@@ -897,6 +897,101 @@ k_shade(DevScene S, int items, int par, RaySrc R, int depthLeft, Pool P) {
   }
 }
 
+// k_classify + k_surface + k_shade in one pass over the level's rays, for scenes
+// in which every hit is a triangle with one of the scene's materials and no
+// material transmits (no k_surface_rest cases, no refraction): a thread that
+// has just looked its hit up goes on to finish the shade point and to spawn the
+// reflected ray, instead of three kernels handing the same hit to each other
+// through memory (hit -> slot list -> position / normal / material -> ray).
+// Shade-point slots and next-level ray slots come from two tile scans.
+__global__ void __launch_bounds__(kBlock)
+k_hit(DevScene S, int items, int par, RaySrc R, int level, int depthLeft, Pool P) {
+  __shared__ TileScan tsHit, tsRefl;
+  __shared__ unsigned int litCount;
+  const long long n = P.counters->n;
+  const size_t rayOff = P.counters->rayOff, spOff = P.counters->spOff;
+  const size_t nextRayOff = rayOff + (size_t)n;
+  const long long perTile = (long long)kBlock * items;
+  checkCoverage(P.counters, gridDim.x * perTile, n);
+  const long long tileBase = blockIdx.x * perTile;
+  if (tileBase >= n) return;   // whole block, uniform
+  // pass 1: which rays hit, which of the hits reflect, how many are lit
+  unsigned int hitMask = 0, reflMask = 0, myLit = 0;
+  for (int k = 0; k < items; k++) {
+    const long long i = tileBase + k * kBlock + threadIdx.x;
+    const int prim = i < n ? P.hitPrim[i] : RT_PRIM_NONE;
+    const bool hit = prim != RT_PRIM_NONE;
+    bool refl = false;
+    if (hit) {
+      const int info = S.faceInfo[prim & ~RT_PRIM_FACE];
+      if (info & RT_FI_LIT) myLit++;
+      refl = depthLeft > 0 && (S.devMats[info & RT_FI_MATERIAL].flags & RT_MATF_KR) != 0;
+    }
+    hitMask |= (hit ? 1u : 0u) << k;
+    reflMask |= (refl ? 1u : 0u) << k;
+    tileCount(tsHit, 0, k, hit);
+    tileCount(tsRefl, 0, k, refl);
+  }
+  if (threadIdx.x == 0) litCount = 0;
+  unsigned int nHit = 0, nRefl = 0, unused = 0;
+  tileReserve(tsHit, items, 1, &P.counters->nsp, nHit, unused);
+  tileReserve(tsRefl, items, 1, &P.counters->nnext, nRefl, unused);
+  if (myLit) atomicAdd(&litCount, myLit);   // LDS atomic
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (nRefl) atomicAdd(&P.counters->refl, (unsigned long long)nRefl);
+    if (litCount) atomicAdd(&P.counters->litsp, (unsigned long long)litCount);
+  }
+  // pass 2: misses turn black, hits become shade points and spawn their reflected ray
+  const int np = par ^ 1;
+  for (int k = 0; k < items; k++) {
+    const long long i = tileBase + k * kBlock + threadIdx.x;
+    const bool hit = (hitMask >> k) & 1u, refl = (reflMask >> k) & 1u;
+    const unsigned int s = tileSlot(tsHit, 0, k, hit);
+    const unsigned int a = tileSlot(tsRefl, 0, k, refl);
+    if (i >= n) continue;
+    if (!hit) {
+      storeV3(P.rayI, P.cap, rayOff + i, V3(0.0, 0.0, 0.0));   // RayTracer.cpp:213-224 (k_background adds a cube map)
+      if (level == 0) P.primaryId[i] = 0;
+      continue;
+    }
+    const size_t g = spOff + s;
+    if (g >= P.cap) {
+      P.counters->overflow = RT_OVERFLOW_POOL;
+      continue;
+    }
+    const int fi = P.hitPrim[i] & ~RT_PRIM_FACE;
+    const int info = S.faceInfo[fi];
+    const RayPD ray = rayAt(S, R, (int)i);
+    Surface sf;
+    surfaceNormalOfFace(S, fi, info, ray.p, ray.d, sf);
+    const V3 Q = ray.p + (P.hitT[i] * ray.d);                            // ray::at (ray.h:42-43)
+    P.spRayGlobal[g] = (int)(rayOff + i);
+    P.spMat[g] = (int)((unsigned int)(info & RT_FI_MATERIAL) | ((info & RT_FI_LIT) ? RT_SPM_LIT : 0u));   // material.cpp:50-53
+    if (level == 0) P.primaryId[i] = sf.objectID;
+    storeV3(P.spQ, P.cap, g, Q);
+    storeV3(P.spN, P.cap, g, sf.N);
+    int childRefl = -1;
+    if (refl) {
+      if (nextRayOff + a >= P.cap) {
+        P.counters->overflow = RT_OVERFLOW_POOL;
+      } else {
+        // RayTracer.cpp:156-164
+        const V3 minusD = -1 * ray.d;
+        const V3 cosVector = sf.N * dot(minusD, sf.N);
+        const V3 sinVector = cosVector + ray.d;
+        const V3 reflDir = normalized(cosVector + sinVector);
+        storeV3(P.rayP[np], P.cap, a, Q);
+        storeV3(P.rayD[np], P.cap, a, reflDir);
+        P.rayType[np][a] = RT_RAY_REFLECTION;
+        childRefl = (int)(nextRayOff + a);
+      }
+    }
+    P.spChildRefl[g] = childRefl;
+    P.spChildRefr[g] = -1;
+  }
+}
+
 // intensity = shade; += kr*traceRay(reflected); += kt*traceRay(refracted)
 // (P.counters: the block of the level that is being combined)
 __global__ void __launch_bounds__(kBlock)
@@ -1249,6 +1344,7 @@ struct RtScene {
   std::map<BatchKey, std::vector<unsigned int>> levelHist;
   std::vector<unsigned int> levelN = std::vector<unsigned int>(kCounterBlocks, 0u);   // level-sync batches: rays per level
   int levelSyncMode = 0;              // RT_AMD_LEVEL_SYNC=1: read every level's count back before the next
+  bool fusedHit = true;               // RT_AMD_FUSED_HIT=0: k_classify / k_surface / k_shade even where k_hit would do
 
   ~RtScene() {
     if (stream) hipStreamSynchronize(stream);
@@ -1565,9 +1661,16 @@ int renderBatch(RenderCtx& cx, long long first, int count, long long* slotsUsed,
     const int items = (int)std::min<long long>(kMaxItems, std::max<long long>(1, est / (kBlock * 2048)));
     const unsigned int tiles = blocksFor(est, kBlock * items);
     const unsigned int dense = blocksFor(est, kBlock);
-    k_classify<<<tiles, kBlock, 0, sc->stream>>>(items, level, P);
-    if (sc->hasFaces) k_surface<<<dense, kBlock, 0, sc->stream>>>(sc->dev, R, level, P);
-    if (sc->surfaceRest) k_surface_rest<<<dense, kBlock, 0, sc->stream>>>(sc->dev, R, level, P);
+    // every hit a plain triangle and nothing refracts: one kernel does what
+    // k_classify, k_surface and k_shade otherwise share out
+    const bool fused = sc->fusedHit && sc->hasFaces && !sc->surfaceRest && sc->dev.opaque;
+    if (fused) {
+      k_hit<<<tiles, kBlock, 0, sc->stream>>>(sc->dev, items, par, R, level, rp.depth - level, P);
+    } else {
+      k_classify<<<tiles, kBlock, 0, sc->stream>>>(items, level, P);
+      if (sc->hasFaces) k_surface<<<dense, kBlock, 0, sc->stream>>>(sc->dev, R, level, P);
+      if (sc->surfaceRest) k_surface_rest<<<dense, kBlock, 0, sc->stream>>>(sc->dev, R, level, P);
+    }
     if (rp.use_cubemap && sc->dev.cube_w > 0)
       k_background<<<dense, kBlock, 0, sc->stream>>>(sc->dev, R, rp.filter_width, P);
     if (overlap) {
@@ -1586,7 +1689,9 @@ int renderBatch(RenderCtx& cx, long long first, int count, long long* slotsUsed,
       HIP_TRY(hipEventRecord(sc->evSide, sc->side));
       sidePending = true;
     }
-    if (sc->dev.opaque)
+    if (fused) {
+      // its rays are spawned already
+    } else if (sc->dev.opaque)
       k_shade<false><<<tiles, kBlock, 0, sc->stream>>>(sc->dev, items, par, R, rp.depth - level, P);
     else
       k_shade<true><<<tiles, kBlock, 0, sc->stream>>>(sc->dev, items, par, R, rp.depth - level, P);
@@ -1841,6 +1946,7 @@ int rt_scene_create(const RtSceneDesc* d, RtScene** out) {
   if (const char* e = std::getenv("RT_AMD_OVERLAP")) sc->overlapMode = std::atoi(e) != 0 ? 1 : 0;
   HIP_TRY(hipHostMalloc((void**)&sc->countersHost, sizeof(Counters) * kCounterBlocks, hipHostMallocDefault));
   if (const char* e = std::getenv("RT_AMD_LEVEL_SYNC")) sc->levelSyncMode = std::atoi(e) != 0 ? 1 : 0;
+  if (const char* e = std::getenv("RT_AMD_FUSED_HIT")) sc->fusedHit = std::atoi(e) != 0;
   HIP_TRY(hipEventCreate(&sc->evStart));
   HIP_TRY(hipEventCreate(&sc->evStop));
   DevScene& D = sc->dev;
