@@ -2165,10 +2165,13 @@ int rt_scene_create(const RtSceneDesc* d, RtScene** out) {
       for (int a = 0; a < 3; a++) {
         D.bvh_bb_min[a] = bvh.rootBox.lo[a];
         D.bvh_bb_max[a] = bvh.rootBox.hi[a];
+        D.bvh_bb_f[a] = rtbvh::down(bvh.rootBox.lo[a]);
+        D.bvh_bb_f[3 + a] = rtbvh::up(bvh.rootBox.hi[a]);
       }
       // 255 * scale + |origin| of every node, bounded from the nodes themselves
       {
         double g[3] = {0.0, 0.0, 0.0};
+        for (int a = 0; a < 3; a++) g[a] = std::max(std::fabs(bvh.rootBox.lo[a]), std::fabs(bvh.rootBox.hi[a]));
         for (const rtbvh::Node4& n4 : wide.nodes) {
           const double sc[3] = {n4.scaleX, n4.scaleY, n4.scaleZ};
           for (int a = 0; a < 3; a++) g[a] = std::max(g[a], 255.0 * sc[a] + std::fabs((double)n4.origin[a]));

@@ -134,6 +134,7 @@ struct DevScene {
   const DevTri* bvhTris;     // triangles in leaf order
   const struct DevTriFast* bvhTrisFast;   // the same triangles, what the hit decision needs only
   double bvh_bb_min[3], bvh_bb_max[3];
+  float bvh_bb_f[6];         // the same box in binary32: lower planes rounded down, then upper planes rounded up
   // per axis, an upper bound of 255 * scale + |origin| over every node of the BVH
   // (what a slab distance's rounding error grows with, see bvhRaySetup)
   float bvhErrG[3];
@@ -661,10 +662,9 @@ __device__ __forceinline__ rt_f2 slab2(uint32_t q, int c, float B, float A) {
 
 // What a query keeps per ray besides p and d.
 struct BvhRay {
-  V3 inv;                 // 1 / d
   V3 ldI;                 // object-space direction of every identity-transform mesh
   double lenI;            // (Geometry::intersect, scene.cpp:17-20: ((p+d)-p) renormalised)
-  float ivx, ivy, ivz;    // inv rounded to binary32
+  float ivx, ivy, ivz;    // 1 / d in binary32
   // -(p * inv) in binary32, moved down (a0*) and up (a1*) by a bound of the
   // rounding error of a plane distance on that axis: what entry and exit plane
   // distances are offset by
@@ -676,25 +676,27 @@ struct BvhRay {
 
 __device__ __forceinline__ void bvhRaySetup(const DevScene& S, const V3& p, const V3& d, int rayType, BvhRay& r) {
   r.cullBack = S.cull && rayType != RT_RAY_REFRACTION;
-  r.inv = V3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
   r.zx = !(fabs(d.x) >= 1.0e-30);
   r.zy = !(fabs(d.y) >= 1.0e-30);
   r.zz = !(fabs(d.z) >= 1.0e-30);
-  r.ivx = (float)r.inv.x; r.ivy = (float)r.inv.y; r.ivz = (float)r.inv.z;
+  // Everything the box tests use is binary32 from the start (three binary64
+  // divisions per ray cost as much as three node visits): inv = 1 / d and
+  // p * inv carry a relative error of 2^-23 and 3 * 2^-24 of their own.
+  r.ivx = 1.0f / (float)d.x; r.ivy = 1.0f / (float)d.y; r.ivz = 1.0f / (float)d.z;
   // A plane at coordinate c lies at distance c * inv - p * inv.  In binary32,
   // with c either a float (bvhNodeSlabsUniform) or origin + q * scale evaluated
-  // as q * (scale * inv) + origin * inv (bvhNodeSlabs), the roundings of the
-  // products, of their sum and of the fused multiply-add stay below
-  // 2^-22 (G |inv| + |p inv|), where G = bvhErrG bounds 255 * scale + |origin|,
-  // and so every |c|, over all nodes.  Entry distances are moved down and exit
-  // distances up by twice that: they stay lower and upper bounds.  (Far from
-  // the world origin the widening grows relative to the boxes: culling gets
-  // weaker, never wrong.)
+  // as q * (scale * inv) + origin * inv (bvhNodeSlabs), the errors of inv and of
+  // p * inv plus the roundings of the products, of their sum and of the fused
+  // multiply-add stay below 2^-21 (G |inv| + |p inv|), where G = bvhErrG bounds
+  // 255 * scale + |origin|, and so every |c|, over all nodes.  Entry distances
+  // are moved down and exit distances up by twice that: they stay lower and
+  // upper bounds.  (Far from the world origin the widening grows relative to
+  // the boxes: culling gets weaker, never wrong.)
   {
-    const float pix = (float)(p.x * r.inv.x), piy = (float)(p.y * r.inv.y), piz = (float)(p.z * r.inv.z);
-    const float ex = 0x1p-21f * fmaf(S.bvhErrG[0], fabsf(r.ivx), fabsf(pix)) + 1.0e-37f;
-    const float ey = 0x1p-21f * fmaf(S.bvhErrG[1], fabsf(r.ivy), fabsf(piy)) + 1.0e-37f;
-    const float ez = 0x1p-21f * fmaf(S.bvhErrG[2], fabsf(r.ivz), fabsf(piz)) + 1.0e-37f;
+    const float pix = (float)p.x * r.ivx, piy = (float)p.y * r.ivy, piz = (float)p.z * r.ivz;
+    const float ex = 0x1p-20f * fmaf(S.bvhErrG[0], fabsf(r.ivx), fabsf(pix)) + 1.0e-37f;
+    const float ey = 0x1p-20f * fmaf(S.bvhErrG[1], fabsf(r.ivy), fabsf(piy)) + 1.0e-37f;
+    const float ez = 0x1p-20f * fmaf(S.bvhErrG[2], fabsf(r.ivz), fabsf(piz)) + 1.0e-37f;
     r.a0x = -pix - ex; r.a1x = -pix + ex;
     r.a0y = -piy - ey; r.a1y = -piy + ey;
     r.a0z = -piz - ez; r.a1z = -piz + ez;
@@ -991,24 +993,20 @@ __device__ int traceBvh(const DevScene& S, const V3& p, const V3& d, int rayType
   BvhRay r;
   bvhRaySetup(S, p, d, rayType, r);
   if (rayType == RT_RAY_VISIBILITY) {   // every other ray starts on a surface, inside the box
-    // Early out for rays that pass the whole structure by (sky): slabs of the
-    // root box with the reciprocals the setup has made anyway, widened so that
-    // rounding can only let a ray through, never turn one away.  An axis whose
-    // products are NaN (0 * inf: origin on a face, direction parallel to it)
-    // constrains nothing.
-    const double kInfD = __longlong_as_double(0x7ff0000000000000LL);
-    double t0 = -kInfD, t1 = kInfD;
-#pragma unroll
-    for (int a = 0; a < 3; a++) {
-      const double lo = (S.bvh_bb_min[a] - p.get(a)) * r.inv.get(a);
-      const double hi = (S.bvh_bb_max[a] - p.get(a)) * r.inv.get(a);
-      const bool ok = (lo == lo) & (hi == hi);
-      const double n = lo < hi ? lo : hi, f = lo < hi ? hi : lo;
-      t0 = (ok & (n > t0)) ? n : t0;
-      t1 = (ok & (f < t1)) ? f : t1;
-    }
-    const double slack = 1.0e-9 * (1.0 + fabs(t0) + fabs(t1));
-    if (t0 > t1 + slack || t1 < -slack) return RT_PRIM_NONE;
+    // Early out for rays that pass the whole structure by (sky): the root box
+    // through the same widened binary32 slab distances as any node (its planes
+    // are within bvhErrG too), so rounding can only let a ray through, never
+    // turn one away.  An axis the ray runs parallel to constrains nothing here.
+    const float kInf = __int_as_float(0x7f800000);
+    const float* bb = S.bvh_bb_f;
+    const float nx = r.zx ? -kInf : fmaf(r.negx ? bb[3] : bb[0], r.ivx, r.a0x);
+    const float fx = r.zx ? kInf : fmaf(r.negx ? bb[0] : bb[3], r.ivx, r.a1x);
+    const float ny = r.zy ? -kInf : fmaf(r.negy ? bb[4] : bb[1], r.ivy, r.a0y);
+    const float fy = r.zy ? kInf : fmaf(r.negy ? bb[1] : bb[4], r.ivy, r.a1y);
+    const float nz = r.zz ? -kInf : fmaf(r.negz ? bb[5] : bb[2], r.ivz, r.a0z);
+    const float fz = r.zz ? kInf : fmaf(r.negz ? bb[2] : bb[5], r.ivz, r.a1z);
+    const float t0 = fmaxf(fmaxf(nx, ny), nz), t1 = fminf(fminf(fx, fy), fz);
+    if (t0 > t1 || t1 < 0.0f) return RT_PRIM_NONE;
   }
   bvhRaySetupLocal(p, d, r);
   bool haveOne = false;
