@@ -904,7 +904,12 @@ k_shade(DevScene S, int items, int par, RaySrc R, int depthLeft, Pool P) {
 // reflected ray, instead of three kernels handing the same hit to each other
 // through memory (hit -> slot list -> position / normal / material -> ray).
 // Shade-point slots and next-level ray slots come from two tile scans.
-__global__ void __launch_bounds__(kBlock)
+// (the kernel waits for its gathers three quarters of the time: five wavefronts
+// per SIMD, with 28 bytes of spill per lane, beat four without and six with 88)
+#ifndef RT_HIT_WAVES
+#define RT_HIT_WAVES 5
+#endif
+__global__ void __launch_bounds__(kBlock, RT_HIT_WAVES)
 k_hit(DevScene S, int items, int par, RaySrc R, int level, int depthLeft, Pool P) {
   __shared__ TileScan tsHit, tsRefl;
   __shared__ unsigned int litCount;
