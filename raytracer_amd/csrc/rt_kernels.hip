@@ -2145,20 +2145,42 @@ int rt_scene_create(const RtSceneDesc* d, RtScene** out) {
       {
         // the same child boxes decoded to binary32 planes, outward rounded
         static_assert(sizeof(DevBvhNodeF) == 128, "float BVH node must be 128 bytes");
-        std::vector<DevBvhNodeF> fn(wide.nodes.size());
-        for (size_t i = 0; i < fn.size(); i++) {
+        // Eight copies per node, copy o for rays whose direction is negative on
+        // the axes of o's set bits, its children sorted near to far along that
+        // diagonal (box centres; unused slots, whose boxes are inverted, last).
+        std::vector<DevBvhNodeF> fn(wide.nodes.size() * 8);
+        for (size_t i = 0; i < wide.nodes.size(); i++) {
           const rtbvh::Node4& n4 = wide.nodes[i];
-          DevBvhNodeF& F = fn[i];
-          std::memset(&F, 0, sizeof F);
-          float* lo[3] = {F.lo_x, F.lo_y, F.lo_z};
-          float* hi[3] = {F.hi_x, F.hi_y, F.hi_z};
           const double sc[3] = {n4.scaleX, n4.scaleY, n4.scaleZ};
-          for (int c = 0; c < 4; c++) {
-            F.child[c] = n4.child[c];
+          float blo[3][4], bhi[3][4];
+          for (int c = 0; c < 4; c++)
             for (int a = 0; a < 3; a++) {
               const double ql = (double)((n4.qlo[a] >> (8 * c)) & 255u), qh = (double)((n4.qhi[a] >> (8 * c)) & 255u);
-              lo[a][c] = rtbvh::down((double)n4.origin[a] + ql * sc[a]);
-              hi[a][c] = rtbvh::up((double)n4.origin[a] + qh * sc[a]);
+              blo[a][c] = rtbvh::down((double)n4.origin[a] + ql * sc[a]);
+              bhi[a][c] = rtbvh::up((double)n4.origin[a] + qh * sc[a]);
+            }
+          for (int o = 0; o < 8; o++) {
+            double key[4];
+            int order[4] = {0, 1, 2, 3};
+            for (int c = 0; c < 4; c++) {
+              bool inverted = false;
+              double k = 0.0;
+              for (int a = 0; a < 3; a++) {
+                inverted |= blo[a][c] > bhi[a][c];
+                const double centre = 0.5 * ((double)blo[a][c] + (double)bhi[a][c]);
+                k += ((o >> a) & 1) ? -centre : centre;
+              }
+              key[c] = inverted ? std::numeric_limits<double>::infinity() : k;
+            }
+            std::stable_sort(order, order + 4, [&](int x, int y) { return key[x] < key[y]; });
+            DevBvhNodeF& F = fn[i * 8 + (size_t)o];
+            std::memset(&F, 0, sizeof F);
+            float* lo[3] = {F.lo_x, F.lo_y, F.lo_z};
+            float* hi[3] = {F.hi_x, F.hi_y, F.hi_z};
+            for (int j = 0; j < 4; j++) {
+              const int c = order[j];
+              F.child[j] = n4.child[c];
+              for (int a = 0; a < 3; a++) { lo[a][j] = blo[a][c]; hi[a][j] = bhi[a][c]; }
             }
           }
         }

@@ -71,9 +71,11 @@ struct DevBvhNode {
 
 // The same node with its child boxes as plain binary32 world-space planes
 // (lower planes rounded down, upper planes up), 128 bytes, axis by axis:
-// lo[a][c] / hi[a][c] = lower / upper plane of child c on axis a.  This copy is
+// lo[a][c] / hi[a][c] = lower / upper plane of child c on axis a.  This form is
 // read through the scalar cache when every lane of a wavefront is at the same
-// node (bvhNodeSlabsUniform); DevBvhNode serves the lanes that are not.
+// node (bvhNodeSlabsUniform); DevBvhNode serves the lanes that are not.  The
+// array holds eight of them per node, number o for rays that run down the axes
+// of o's set bits, with the children sorted near to far for such rays.
 struct DevBvhNodeF {
   float lo_x[4], hi_x[4], lo_y[4], hi_y[4], lo_z[4], hi_z[4];
   int child[4];
@@ -814,9 +816,11 @@ typedef int rt_i4 __attribute__((ext_vector_type(4)));
 // inv, widened by the ray's error bound: |plane| <= bvhErrG, so the bound of
 // bvhRaySetup covers the roundings of this form as well.
 __device__ __forceinline__ void bvhNodeSlabsUniform(const DevScene& S, const BvhRay& r, int ref, unsigned int negMask,
-                                                    float bestTf, float tn[4], int kid[4]) {
+                                                    unsigned int copy, float bestTf, float tn[4], int kid[4]) {
   const float kInf = __int_as_float(0x7f800000);
-  const char* np = reinterpret_cast<const char*>(S.bvhF + ref);
+  // eight copies of every node, one per combination of direction signs, each
+  // with its children listed near to far for directions of those signs
+  const char* np = reinterpret_cast<const char*>(S.bvhF + ((size_t)ref * 8 + copy));
   // entry planes of an axis: the lower ones unless the rays run down that axis
   const unsigned int oNX = (negMask & 1u) ? 16u : 0u, oNY = (negMask & 2u) ? 48u : 32u, oNZ = (negMask & 4u) ? 80u : 64u;
   const unsigned int oFX = oNX ^ 16u, oFY = oNY ^ 16u, oFZ = oNZ ^ 16u;
@@ -1095,10 +1099,34 @@ __device__ int traceBvh(const DevScene& S, const V3& p, const V3& d, int rayType
       // also carry the code of the other primitive kinds its 28 scalar registers
       // push vector registers over an occupancy step.)
       const int uref = __builtin_amdgcn_readfirstlane(ref);
-      if (TRI && uniformOk && __ballot(ref != uref) == 0) bvhNodeSlabsUniform(S, r, uref, negMask, bestTf, tn, kid);
+      if (TRI && !ANYHIT && uniformOk && __ballot(ref != uref) == 0) {
+        bvhNodeSlabsUniform(S, r, uref, negMask, negMask, bestTf, tn, kid);
+        // The children of this copy of the node come near to far for rays of
+        // these direction signs (by box centre along the signs' diagonal, fixed
+        // when the scene was created): the first one hit is next, the others go
+        // onto the stack farthest first.  No per-lane sort, and the child
+        // references stay in scalar registers.  The order is only nearly the
+        // order of entry distances; a closer hit found late still culls what was
+        // pushed before it (pop), so the result does not depend on it.
+        const bool h0 = tn[0] < kInf, h1 = tn[1] < kInf, h2 = tn[2] < kInf, h3 = tn[3] < kInf;
+        if (h3 & (h0 | h1 | h2)) RT_BVH_PUSH(kid[3], tn[3])
+        if (h2 & (h0 | h1)) RT_BVH_PUSH(kid[2], tn[2])
+        if (h1 & h0) RT_BVH_PUSH(kid[1], tn[1])
+        if (h0 | h1 | h2 | h3) {
+          ref = h0 ? kid[0] : h1 ? kid[1] : h2 ? kid[2] : kid[3];
+          continue;
+        }
+      } else
+#endif
+      {
+#ifndef RT_NO_UNIFORM_PATH
+      // (occlusion queries visit every overlapped subtree whatever the order:
+      // they all read copy 0 and pick the nearest child as below)
+      // (measured: taking the first overlapped child instead costs 8 %)
+      if (TRI && ANYHIT && uniformOk && __ballot(ref != uref) == 0) bvhNodeSlabsUniform(S, r, uref, negMask, 0u, bestTf, tn, kid);
       else
 #endif
-        bvhNodeSlabs(S, p, r, ref, bestTf, tn, kid);
+      bvhNodeSlabs(S, p, r, ref, bestTf, tn, kid);
       if (ANYHIT) {
         // Every overlapped subtree has to be searched unless an occluder turns
         // up, so only the descent wants an order: nearest child next, the
@@ -1125,6 +1153,7 @@ __device__ int traceBvh(const DevScene& S, const V3& p, const V3& d, int rayType
           ref = kid[0];
           continue;
         }
+      }
       }
     } else {
       double tHit;
