@@ -349,7 +349,7 @@ k_trace(DevScene S, RaySrc R, double* hitT, int* hitPrim, Counters* counters) {
     double t = 0.0;
     if (type >= 0) {
       if (FAST) prim = traceBvh<false, STATS, TRI>(S, p, d, type, 1.0e308, -1.0, t, tc, (rt_lds_u32*)rtStackLds);
-      else prim = traceKdReference<STATS>(S, p, d, type, t, tc);
+      else prim = traceKdReference<STATS>(S, p, d, type, t, tc, (rt_kd_lds_u32*)rtStackLds);
     }
     hitT[i] = t;
     hitPrim[i] = prim;
@@ -589,7 +589,7 @@ __device__ __forceinline__ void shadowQuery(const DevScene& S, const RtLight& l,
     const V3 sd = normalized(-V3(l.orientation));
     // any hit blacks a directional light out (light.cpp:21-24)
     if (FAST) prim = traceBvh<true, STATS, TRI>(S, Q, sd, RT_RAY_SHADOW, 1.0e308, -1.0, th, tc, (rt_lds_u32*)rtStackLds);
-    else prim = traceKdReference<STATS>(S, Q, sd, RT_RAY_SHADOW, th, tc);
+    else prim = traceKdReference<STATS>(S, Q, sd, RT_RAY_SHADOW, th, tc, (rt_kd_lds_u32*)rtStackLds);
     return;
   }
   const V3 position(l.position);
@@ -607,7 +607,7 @@ __device__ __forceinline__ void shadowQuery(const DevScene& S, const RtLight& l,
   } else if (FAST) {
     prim = traceBvh<false, STATS, TRI>(S, Q, sd, RT_RAY_SHADOW, limit, -1.0, th, tc, (rt_lds_u32*)rtStackLds);
   } else {
-    prim = traceKdReference<STATS>(S, Q, sd, RT_RAY_SHADOW, th, tc);
+    prim = traceKdReference<STATS>(S, Q, sd, RT_RAY_SHADOW, th, tc, (rt_kd_lds_u32*)rtStackLds);
   }
 }
 
@@ -1099,7 +1099,7 @@ k_intersect(DevScene S, int n, const double* rays, const int* types, RtHit* hits
   TraceCounters tc{0, 0, 0};
   double t;
   const int prim = FAST ? traceBvh<false, false>(S, p, d, type, 1.0e308, -1.0, t, tc, (rt_lds_u32*)rtStackLds)
-                        : traceKdReference<false>(S, p, d, type, t, tc);
+                        : traceKdReference<false>(S, p, d, type, t, tc, (rt_kd_lds_u32*)rtStackLds);
   RtHit h;
   h.t = 1000.0;                      // scene.cpp:155
   h.N[0] = h.N[1] = h.N[2] = 0.0;
@@ -1552,7 +1552,7 @@ inline unsigned int blocksFor(long long est, int threads) {
 template <bool FAST, bool STATS>
 void launchTrace(RtScene* sc, const Pool& P, long long est, const RaySrc& R) {
   const unsigned int blocks = blocksFor(est, kTraceBlock);
-  const size_t lds = FAST ? (size_t)RT_LDS_STACK_BYTES_CLOSEST * kTraceBlock : 0;
+  const size_t lds = (size_t)(FAST ? RT_LDS_STACK_BYTES_CLOSEST : RT_KD_LDS_STACK_BYTES) * kTraceBlock;
   if (FAST && sc->triOnly)
     k_trace<FAST, STATS, true><<<blocks, kTraceBlock, lds, sc->stream>>>(sc->dev, R, P.hitT, P.hitPrim, P.counters);
   else
@@ -1563,7 +1563,8 @@ void launchShadow(RtScene* sc, hipStream_t st, const Pool& P, long long est) {
   const dim3 grid(blocksFor(est, kTraceBlock), (unsigned int)sc->dev.n_lights);
   // opaque scenes: occlusion queries (4-byte stack entries) except for directional
   // lights, which use them anyway; otherwise closest-hit queries bounded by the light
-  const size_t lds = !FAST ? 0 : (size_t)(sc->dev.opaque ? RT_LDS_STACK_BYTES_ANYHIT : RT_LDS_STACK_BYTES_CLOSEST) * kTraceBlock;
+  const size_t lds = (size_t)(!FAST ? RT_KD_LDS_STACK_BYTES
+                                    : sc->dev.opaque ? RT_LDS_STACK_BYTES_ANYHIT : RT_LDS_STACK_BYTES_CLOSEST) * kTraceBlock;
   if (FAST && sc->triOnly)
     k_shadow<FAST, STATS, true><<<grid, kTraceBlock, lds, st>>>(sc->dev, P);
   else
@@ -2574,7 +2575,8 @@ int rt_intersect_batch(RtScene* sc, int traversal, int n, const double* rays_pd,
     k_intersect<true><<<gridFor(n), kBlock, (size_t)RT_LDS_STACK_BYTES_CLOSEST * kBlock, sc->stream>>>(
         sc->dev, n, rays.as<double>(), types.as<int>(), hitBuf.as<RtHit>());
   else
-    k_intersect<false><<<gridFor(n), kBlock, 0, sc->stream>>>(sc->dev, n, rays.as<double>(), types.as<int>(), hitBuf.as<RtHit>());
+    k_intersect<false><<<gridFor(n), kBlock, (size_t)RT_KD_LDS_STACK_BYTES * kBlock, sc->stream>>>(
+        sc->dev, n, rays.as<double>(), types.as<int>(), hitBuf.as<RtHit>());
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(hits, hitBuf.p, (size_t)n * sizeof(RtHit), hipMemcpyDeviceToHost, sc->stream));
   HIP_TRY(hipStreamSynchronize(sc->stream));
@@ -2601,7 +2603,8 @@ int rt_intersect_batch_static(RtScene* sc, int traversal, int n, const double* r
     k_intersect<true><<<gridFor(n), kBlock, (size_t)RT_LDS_STACK_BYTES_CLOSEST * kBlock, sc->stream>>>(
         sc->dev, n, raysDev, typesArg, hitsDev);
   else
-    k_intersect<false><<<gridFor(n), kBlock, 0, sc->stream>>>(sc->dev, n, raysDev, typesArg, hitsDev);
+    k_intersect<false><<<gridFor(n), kBlock, (size_t)RT_KD_LDS_STACK_BYTES * kBlock, sc->stream>>>(sc->dev, n, raysDev, typesArg,
+                                                                                                  hitsDev);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(hits, hitsDev, (size_t)n * sizeof(RtHit), hipMemcpyDeviceToHost, sc->stream));
   HIP_TRY(hipStreamSynchronize(sc->stream));

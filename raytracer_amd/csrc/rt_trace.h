@@ -468,11 +468,23 @@ __device__ __forceinline__ bool faceBoxCull(const DevTri& T, const V3& p, const 
 
 struct KdEntry { uint32_t node; double tmin, tmax; };
 
+// The first RT_KD_LDS_STACK entries of a lane's stack live in the workgroup's
+// LDS as three planes -- node words, then lower, then upper interval ends, each
+// [entry][thread] -- so that a wavefront's accesses fall on 64 different banks;
+// deeper entries go to a per-lane array in scratch memory.  The intervals stay
+// binary64: they are compared with tStar exactly as the reference compares them.
+#ifndef RT_KD_LDS_STACK
+#define RT_KD_LDS_STACK 8
+#endif
+#define RT_KD_LDS_STACK_BYTES (RT_KD_LDS_STACK * 20)   // per thread
+typedef __attribute__((address_space(3))) uint32_t rt_kd_lds_u32;
+typedef __attribute__((address_space(3))) double rt_kd_lds_f64;
+
 // Scene::intersect with the reference's own traversal.  Returns the winning
 // primitive (RT_PRIM_NONE on a miss) and its world-space t.
 template <bool STATS>
 __device__ int traceKdReference(const DevScene& S, const V3& p, const V3& d, int rayType,
-                                double& tOut, TraceCounters& cnt) {
+                                double& tOut, TraceCounters& cnt, rt_kd_lds_u32* ldsStack) {
   bool haveOne = false;
   double bestT = 0.0;
   int bestPrim = RT_PRIM_NONE;
@@ -517,15 +529,28 @@ __device__ int traceKdReference(const DevScene& S, const V3& p, const V3& d, int
     return bestPrim;
   }
 
-  KdEntry stack[RT_STACK_DEPTH];
+  KdEntry deep[RT_STACK_DEPTH - RT_KD_LDS_STACK];   // entries past the LDS part
+  const unsigned int ldsStride = blockDim.x;
+  rt_kd_lds_u32* const colNode = ldsStack + threadIdx.x;
+  rt_kd_lds_f64* const colMin = (rt_kd_lds_f64*)(ldsStack + RT_KD_LDS_STACK * ldsStride) + threadIdx.x;
+  rt_kd_lds_f64* const colMax = colMin + RT_KD_LDS_STACK * ldsStride;
+#define RT_KD_PUSH(NODE, TMIN, TMAX)                                               \
+  {                                                                                \
+    if (sp < RT_KD_LDS_STACK) {                                                    \
+      colNode[(unsigned int)sp * ldsStride] = (uint32_t)(NODE);                    \
+      colMin[(unsigned int)sp * ldsStride] = (TMIN);                               \
+      colMax[(unsigned int)sp * ldsStride] = (TMAX);                               \
+    } else {                                                                       \
+      KdEntry& e_ = deep[sp - RT_KD_LDS_STACK];                                    \
+      e_.node = (uint32_t)(NODE); e_.tmin = (TMIN); e_.tmax = (TMAX);              \
+    }                                                                              \
+    sp++;                                                                          \
+  }
   int sp = 0;
   // function-level interval of the reference's current intersectKdTree call
   double fMin = 0.0, fMax = 0.0;
   boxIntersect(S.scene_bb_min, S.scene_bb_max, p, d, fMin, fMax);  // result ignored (scene.cpp:139)
-  stack[sp].node = (uint32_t)S.scene_root;
-  stack[sp].tmin = fMin;
-  stack[sp].tmax = fMax;
-  sp++;
+  RT_KD_PUSH(S.scene_root, fMin, fMax)
   const double sceneFMin = fMin, sceneFMax = fMax;
   bool inMesh = false;
   LocalRay lr;
@@ -533,17 +558,25 @@ __device__ int traceKdReference(const DevScene& S, const V3& p, const V3& d, int
 
   while (sp > 0) {
     --sp;
-    uint32_t nidx = stack[sp].node;
+    uint32_t nidx;
+    double eMin, eMax;
+    if (sp < RT_KD_LDS_STACK) {
+      nidx = colNode[(unsigned int)sp * ldsStride];
+      eMin = colMin[(unsigned int)sp * ldsStride];
+      eMax = colMax[(unsigned int)sp * ldsStride];
+    } else {
+      const KdEntry& e_ = deep[sp - RT_KD_LDS_STACK];
+      nidx = e_.node; eMin = e_.tmin; eMax = e_.tmax;
+    }
     int k0 = 0;
     if (nidx & RT_ENTRY_RESUME) {
       // back in the scene-level leaf loop after a nested mesh traversal
       nidx &= ~RT_ENTRY_RESUME;
-      k0 = (int)stack[sp].tmin;
+      k0 = (int)eMin;
       inMesh = false;
       fMin = sceneFMin;
       fMax = sceneFMax;
     }
-    const double eMin = stack[sp].tmin, eMax = stack[sp].tmax;
     const DevNode nd = S.nodes[nidx];
     if (STATS) cnt.nodes++;
     if ((nd.a & 3u) == 3u) {
@@ -558,14 +591,8 @@ __device__ int traceKdReference(const DevScene& S, const V3& p, const V3& d, int
             boxIntersect(m.root_bb_min, m.root_bb_max, p, d, a0, a1);  // result ignored (scene.cpp:79)
             if (m.kd_root < 0) continue;
             if (sp + 2 > RT_STACK_DEPTH) continue;
-            stack[sp].node = nidx | RT_ENTRY_RESUME;
-            stack[sp].tmin = (k + 1);
-            stack[sp].tmax = 0;
-            sp++;
-            stack[sp].node = (uint32_t)m.kd_root;
-            stack[sp].tmin = a0;
-            stack[sp].tmax = a1;
-            sp++;
+            RT_KD_PUSH(nidx | RT_ENTRY_RESUME, (double)(k + 1), 0.0)
+            RT_KD_PUSH(m.kd_root, a0, a1)
             inMesh = true;
             fMin = a0;
             fMax = a1;
@@ -603,15 +630,16 @@ __device__ int traceKdReference(const DevScene& S, const V3& p, const V3& d, int
       if (po < nd.split) { nearN = left; farN = right; } else { nearN = right; farN = left; }
       if (sp + 2 > RT_STACK_DEPTH) continue;
       if (tStar > eMax || tStar < 0) {
-        stack[sp].node = nearN; stack[sp].tmin = fMin; stack[sp].tmax = fMax; sp++;
+        RT_KD_PUSH(nearN, fMin, fMax)
       } else if (tStar < eMin) {
-        stack[sp].node = farN; stack[sp].tmin = fMin; stack[sp].tmax = fMax; sp++;
+        RT_KD_PUSH(farN, fMin, fMax)
       } else if (eMin <= tStar && tStar <= eMax) {
-        stack[sp].node = nearN; stack[sp].tmin = fMin; stack[sp].tmax = tStar; sp++;
-        stack[sp].node = farN; stack[sp].tmin = tStar; stack[sp].tmax = fMax; sp++;
+        RT_KD_PUSH(nearN, fMin, tStar)
+        RT_KD_PUSH(farN, tStar, fMax)
       }
     }
   }
+#undef RT_KD_PUSH
   tOut = bestT;
   return bestPrim;
 }
