@@ -614,6 +614,7 @@ __device__ __forceinline__ void shadowQuery(const DevScene& S, const RtLight& l,
 // distanceAttenuation * shadowAttenuation of one light (material.cpp:59-60,
 // light.cpp:14-149) from the outcome of its shadow query, and the direction L
 // to the light as Material::shade normalises it.
+template <bool INTPOW>
 __device__ __forceinline__ V3 lightIntensityFrom(const DevScene& S, const RtLight& l, const double* cone, const V3& Q,
                                                  int prim, double th, bool anyOccluder, V3& L) {
   const V3 color(l.color);
@@ -661,7 +662,7 @@ __device__ __forceinline__ V3 lightIntensityFrom(const DevScene& S, const RtLigh
       if (outside) {
         atten = V3(0.0, 0.0, 0.0);
       } else {
-        const double fallFactor = pow(x, l.fall_rate);
+        const double fallFactor = INTPOW ? powNearInt(x, (int)cone[2], cone[3]) : pow(x, l.fall_rate);
         atten = occluded ? prod((color * fallFactor), kt) : (color * fallFactor);
       }
     }
@@ -713,6 +714,7 @@ k_shadow(DevScene S, Pool P) {
 // Material::shade of shade point s (material.cpp:41-75): the emissive + ambient
 // base, then per light in scene order the attenuation from its shadow query and
 // the diffuse and specular terms, added in the reference's order.
+template <bool INTPOW>
 __device__ __forceinline__ void shadePoint(const DevScene& S, const Pool& P, int s, size_t g, unsigned int mw,
                                            const V3& Q, const V3& N) {
   const bool interp = (mw & RT_SPM_INTERP) != 0;
@@ -722,7 +724,8 @@ __device__ __forceinline__ void shadePoint(const DevScene& S, const Pool& P, int
     return;
   }
   V3 kd, ks, I;
-  double shin;
+  double shin, shinD = 0.0;
+  int shinN = 0;
   if (interp) {
     kd = loadV3(P.spKd, P.cap, g);
     ks = loadV3(P.spKs, P.cap, g);
@@ -733,6 +736,8 @@ __device__ __forceinline__ void shadePoint(const DevScene& S, const Pool& P, int
     kd = V3(dm.kd);
     ks = V3(dm.ks);
     shin = dm.shin;
+    shinN = dm.shinN;
+    shinD = dm.shinD;
     I = V3(dm.base);
   }
   const bool hasKd = !iszero(kd), hasKs = !iszero(ks);
@@ -743,7 +748,7 @@ __device__ __forceinline__ void shadePoint(const DevScene& S, const Pool& P, int
     const int sp = P.shPrim[o];
     const double th = P.shT ? P.shT[o] : 0.0;
     V3 L;
-    const V3 lightIntensity = lightIntensityFrom(S, S.lights[li], S.spotCone + 2 * li, Q,
+    const V3 lightIntensity = lightIntensityFrom<INTPOW>(S, S.lights[li], S.spotCone + 4 * li, Q,
                                                  sp == RT_PRIM_ANY ? RT_PRIM_NONE : sp, th, sp == RT_PRIM_ANY, L);
     // A light that contributes exactly zero (occluded by an opaque surface,
     // outside a spot cone) adds +0 to every component when the Phong factors are
@@ -763,7 +768,7 @@ __device__ __forceinline__ void shadePoint(const DevScene& S, const Pool& P, int
       const double c = dot(refl, view);
       const double base = (c < 0.0) ? 0.0 : c;
       // pow(0, y) is 0 for y > 0: the highlight's far side needs no pow
-      const double spec = (base == 0.0 && shin > 0.0) ? 0.0 : pow(base, shin);
+      const double spec = (base == 0.0 && shin > 0.0) ? 0.0 : INTPOW ? powNearInt(base, shinN, shinD) : pow(base, shin);
       I = I + prod(ks, lightIntensity) * spec;
     }
   }
@@ -773,6 +778,10 @@ __device__ __forceinline__ void shadePoint(const DevScene& S, const Pool& P, int
 // One thread per shade point: its colour.  (Folding this into k_shade's first
 // pass was measured slower: a thread there walks up to 16 points one after the
 // other, and pow / acos want the parallelism of a dense launch.)
+// INTPOW: every exponent of the scene (shininess of each material, fall_rate of
+// each spot light) is a small non-negative integer up to rounding, and no
+// material is interpolated: powNearInt instead of pow.
+template <bool INTPOW>
 __global__ void __launch_bounds__(kBlock)
 k_lights(DevScene S, Pool P) {
   const long long nsp = shadePointsOf(P);
@@ -780,7 +789,7 @@ k_lights(DevScene S, Pool P) {
   const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= nsp) return;
   const size_t g = (size_t)P.counters->spOff + s;
-  shadePoint(S, P, (int)s, g, (unsigned int)P.spMat[g], loadV3(P.spQ, P.cap, g), loadV3(P.spN, P.cap, g));
+  shadePoint<INTPOW>(S, P, (int)s, g, (unsigned int)P.spMat[g], loadV3(P.spQ, P.cap, g), loadV3(P.spN, P.cap, g));
 }
 
 // The secondary rays of RayTracer::traceRay (RayTracer.cpp:152-201).  Reflected rays of a tile are
@@ -1349,6 +1358,7 @@ struct RtScene {
   std::map<BatchKey, std::vector<unsigned int>> levelHist;
   std::vector<unsigned int> levelN = std::vector<unsigned int>(kCounterBlocks, 0u);   // level-sync batches: rays per level
   int levelSyncMode = 0;              // RT_AMD_LEVEL_SYNC=1: read every level's count back before the next
+  bool intPow = true;                 // every pow exponent of the scene is near a small integer: k_lights<true>
   bool fusedHit = true;               // RT_AMD_FUSED_HIT=0: k_classify / k_surface / k_shade even where k_hit would do
 
   ~RtScene() {
@@ -1376,6 +1386,17 @@ struct RtScene {
 };
 
 namespace {
+
+// v = n + delta with n a non-negative integer below 2^20 and |delta| <= 1e-12:
+// what powNearInt takes for an exponent.
+bool nearSmallInt(double v, int& n, double& delta) {
+  if (!(v >= -1.0e-12 && v < 1048576.0)) return false;
+  const double r = std::floor(v + 0.5);
+  if (std::fabs(v - r) > 1.0e-12) return false;
+  n = (int)r;
+  delta = v - r;
+  return true;
+}
 
 // Depth of a subtree and validation of child / item indices.
 int treeDepth(const RtSceneDesc& d, int root, int itemLimit, std::string& err) {
@@ -1690,7 +1711,8 @@ int renderBatch(RenderCtx& cx, long long first, int count, long long* slotsUsed,
       if (timed2) timedEnd(sc, lightStream, 1);
       cx.stats.lights_launches++;
     }
-    k_lights<<<dense, kBlock, 0, lightStream>>>(sc->dev, P);
+    if (sc->intPow) k_lights<true><<<dense, kBlock, 0, lightStream>>>(sc->dev, P);
+    else k_lights<false><<<dense, kBlock, 0, lightStream>>>(sc->dev, P);
     if (overlap) {
       HIP_TRY(hipEventRecord(sc->evSide, sc->side));
       sidePending = true;
@@ -2213,7 +2235,7 @@ int rt_scene_create(const RtSceneDesc* d, RtScene** out) {
   { RtMaterial* p; HIP_TRY(upload(d->materials, (size_t)d->n_materials, &p)); keep(p); D.materials = p; }
   { RtLight* p; HIP_TRY(upload(d->lights, (size_t)d->n_lights, &p)); keep(p); D.lights = p; }
   {
-    std::vector<double> cone(2 * (size_t)std::max(1, d->n_lights), 0.0);
+    std::vector<double> cone(4 * (size_t)std::max(1, d->n_lights), 0.0);
     for (int li = 0; li < d->n_lights; li++) {
       // outside: angle > atten + hair  <=>  x < cos(that); inside: angle < atten - hair.
       // The hair (1.7e-11 rad) is far above the rounding of cos and acos as long
@@ -2221,8 +2243,14 @@ int rt_scene_create(const RtSceneDesc* d, RtScene** out) {
       // steep; such cones (and angles outside [0, 180]) keep the acos for every x.
       const double a = d->lights[li].atten_angle, hair = 1e-9;
       const bool plain = a > 0.01 && a < 179.99;
-      cone[2 * li] = plain ? std::cos((a + hair) * M_PI / 180.0) : -2.0;
-      cone[2 * li + 1] = plain ? std::cos((a - hair) * M_PI / 180.0) : 2.0;
+      cone[4 * li] = plain ? std::cos((a + hair) * M_PI / 180.0) : -2.0;
+      cone[4 * li + 1] = plain ? std::cos((a - hair) * M_PI / 180.0) : 2.0;
+      if (d->lights[li].type == RT_LIGHT_SPOT) {
+        int n;
+        double delta;
+        if (nearSmallInt(d->lights[li].fall_rate, n, delta)) { cone[4 * li + 2] = n; cone[4 * li + 3] = delta; }
+        else sc->intPow = false;
+      }
     }
     double* p; HIP_TRY(upload(cone.data(), cone.size(), &p)); keep(p); D.spotCone = p;
   }
@@ -2241,6 +2269,11 @@ int rt_scene_create(const RtSceneDesc* d, RtScene** out) {
       const double si = (0.299 * M.shininess[0]) + (0.587 * M.shininess[1]) + (0.114 * M.shininess[2]);
       o.shin = M.shininess_mapped ? 128.0 * si : si;
       o.ior = (0.299 * M.index[0]) + (0.587 * M.index[1]) + (0.114 * M.index[2]);
+      if (!nearSmallInt(o.shin, o.shinN, o.shinD)) {
+        o.shinN = -1;
+        o.shinD = 0.0;
+        if (nz(M.ks)) sc->intPow = false;   // (a material without a highlight never reaches pow)
+      }
       o.flags = (nz(M.kd) ? RT_MATF_KD : 0) | (nz(M.ks) ? RT_MATF_KS : 0) | (nz(M.kr) ? RT_MATF_KR : 0) |
                 (nz(M.kt) ? RT_MATF_KT : 0);
     }
@@ -2253,6 +2286,8 @@ int rt_scene_create(const RtSceneDesc* d, RtScene** out) {
   if (d->smooth_shading)
     for (int m = 0; m < d->n_meshes; m++)
       if (d->meshes[m].has_vertex_materials) D.interp_materials = 1;
+  if (D.interp_materials) sc->intPow = false;   // interpolated shininess is anything
+  if (const char* e = std::getenv("RT_AMD_INT_POW")) { if (std::atoi(e) == 0) sc->intPow = false; }
   D.faceInfo = nullptr;
   if (d->n_faces > 0) {
     if (d->n_materials > RT_FI_MATERIAL) return fail(RT_ERR_UNSUPPORTED, "too many materials");

@@ -90,7 +90,8 @@ struct DevMat {
   double shin;      // Material::shininess            (material.h:209-215)
   double ior;       // Material::index as a scalar    (material.h:217)
   int flags;        // RT_MATF_*
-  int pad;
+  int shinN;        // shininess = shinN + shinD with |shinD| <= 1e-12 when it is that close to a small
+  double shinD;     // non-negative integer (powNearInt), else shinN = -1
 };
 #define RT_MATF_KD 1   // kd != 0
 #define RT_MATF_KS 2
@@ -120,7 +121,7 @@ struct DevScene {
   // light's cone test acos(x) * 180 / pi > atten_angle (light.cpp:129-133,141-145)
   // is decided by x against these two wherever x is not within that hair of the
   // cone's edge; only there is the acos itself needed.
-  const double* spotCone;
+  const double* spotCone;      // per light: cosines bracketing the cone's edge, then fall_rate as n, delta (powNearInt)
   const double* vnormals;    // 3 per global vertex
   const double* face_normals;  // 9 per face: the vertex normals of its corners (NULL: none / flat shading)
   const int* faceInfo;         // RT_FI_* word per face: what a hit needs to know about its mesh and owner

@@ -388,3 +388,36 @@ def test_level_estimates_and_the_redo_of_an_outgrown_batch(built, monkeypatch):
         ds.close()
     assert np.array_equal(frames[0][0], frames[1][0]) and np.array_equal(frames[0][1], frames[1][1])
     assert frames[0][2:] == frames[1][2:]
+
+
+def test_near_integer_exponents_without_the_general_power(built, monkeypatch):
+    """Scenes whose shininess and spot fall-off exponents are small integers up
+    to rounding (32 arrives as 31.999999999999996 through Material::shininess's
+    weighted sum) shade with an exact integer power in double-double arithmetic
+    instead of pow (RT_AMD_INT_POW=0 switches back).  Both must agree with the
+    oracle's libm pow to the tolerance of every parity test."""
+    s = scenes.HEADER
+    s += scenes.camera((0.0371, 1.5137, -6.0213), (0.0, -0.15, 1.0), aspect=1.0, fov=40.0)
+    s += scenes.ambient_light((0.1, 0.1, 0.1))
+    s += scenes.point_light((3.1237, 4.3411, -4.2173))
+    s += scenes.spot_light((-2.2119, 5.1273, -1.3371), (0.3, -1.0, 0.2), color=(0.9, 0.9, 0.8), atten_angle=40.0,
+                           fall_rate=6.0)
+    for k, shin in enumerate((1.0, 8.0, 32.0, 64.0, 100.0, 0.0)):
+        m = scenes.material(diffuse=(0.4, 0.3 + 0.05 * k, 0.5), specular=(0.7, 0.7, 0.7), shininess=shin,
+                            ambient=(0.3, 0.3, 0.3), reflective=(0.2, 0.2, 0.2))
+        s += scenes.translate((-2.5 + k * 1.0113, 0.9 + 0.1 * k, 0.5117 * k), scenes.scale((0.5, 0.5, 0.5),
+                                                                                            scenes.prim("sphere", m)))
+    floor = scenes.material(diffuse=(0.5, 0.5, 0.5), specular=(0.3, 0.3, 0.3), shininess=16.0, ambient=(0.4, 0.4, 0.4))
+    s += scenes.translate((0.0, 0.0, 2.0), scenes.rotate((1, 0, 0), -1.5707963, scenes.scale((12.0, 12.0, 1.0),
+                                                                                        scenes.prim("square", floor))))
+    hs = host.HostScene(text=s)
+    p, _ = host.render_params(160, 160, depth=2, traversal=abi.RT_TRAVERSE_FAST)
+    ref_rgb, ref_hits, ref_st = loader.render(hs.desc_ptr, p, threads=8)
+    assert ref_rgb.reshape(-1, 3).max(axis=1).mean() > 40
+    for setting in ("1", "0"):
+        monkeypatch.setenv("RT_AMD_INT_POW", setting)
+        ds = device.DeviceScene(hs.desc_ptr)
+        rgb, hits, st = ds.render(p)
+        ds.close()
+        common.assert_parity(rgb, hits, ref_rgb, ref_hits, what="RT_AMD_INT_POW=" + setting)
+        assert _ray_counts(st) == _ray_counts(ref_st)
