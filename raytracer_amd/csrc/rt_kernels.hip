@@ -222,7 +222,7 @@ struct RaySrc {
   const int* parent;      // pool index of the shade point a queued ray starts at
   const double* spQ;      // shade-point positions (Pool::spQ)
   const double* d;
-  const int* type;
+  const int* type;        // NULL: every ray of the queue is a reflected one (k_hit's queues)
   size_t stride;
   int primary;            // 1: level 0
   FrameMap fm;
@@ -276,11 +276,17 @@ __device__ __forceinline__ void dropChild(const RaySrc& R, int* spChildRefl, int
   else spChildRefl[g] = -1;
 }
 
+// Sample i of a batch is the first of its pixel: the one whose hit id the frame
+// shows (k_resolve), the only one whose id is stored.
+__device__ __forceinline__ bool firstSampleOfPixel(const FrameMap& fm, long long i) {
+  return (unsigned int)i == fastDiv((unsigned int)i, fm.dNs) * fm.dNs.d;
+}
+
 // Ray i of the level.
 __device__ __forceinline__ RayPD rayAt(const DevScene& S, const RaySrc& R, int i) {
   if (R.primary) return primaryRay(S, R.fm, R.first, i);
   RayPD r;
-  r.type = R.type[i];
+  r.type = R.type ? R.type[i] : RT_RAY_REFLECTION;
   if (r.type >= 0) {
     r.p = loadV3(R.spQ, R.stride, (size_t)R.parent[i]);
     r.d = loadV3(R.d, R.stride, i);
@@ -487,7 +493,7 @@ k_classify(int items, int level, RaySrc R, int blackMiss, Pool P) {
         } else {
           storeV3(P.rayI, P.cap, rayOff + i, V3(0.0, 0.0, 0.0));
         }
-        if (level == 0) P.primaryId[i] = 0;
+        if (level == 0 && firstSampleOfPixel(R.fm, i)) P.primaryId[i] = 0;
       } else if (spOff + s >= P.cap) {
         P.counters->overflow = RT_OVERFLOW_POOL;
       } else {
@@ -530,7 +536,7 @@ k_surface(DevScene S, RaySrc R, int level, Pool P) {
     Surface sf;
     surfaceNormalOfFace(S, fi, info, p, d, sf);
     P.spMat[g] = (int)((unsigned int)(info & RT_FI_MATERIAL) | ((info & RT_FI_LIT) ? RT_SPM_LIT : 0u));   // material.cpp:50-53
-    if (level == 0) P.primaryId[i] = sf.objectID;
+    if (level == 0 && firstSampleOfPixel(R.fm, i)) P.primaryId[i] = sf.objectID;
     const V3 Q = p + (P.hitT[i] * d);                                    // ray::at (ray.h:42-43)
     storeV3(P.spQ, P.cap, g, Q);
     storeV3(P.spN, P.cap, g, sf.N);
@@ -575,7 +581,7 @@ k_surface_rest(DevScene S, RaySrc R, int level, Pool P) {
         storeV3(P.spKt, P.cap, g, m.kt);
         P.spIor[g] = intensityValue(m.index);                              // Material::index (material.h:217)
       }
-      if (level == 0) P.primaryId[i] = sf.objectID;
+      if (level == 0 && firstSampleOfPixel(R.fm, i)) P.primaryId[i] = sf.objectID;
       const V3 Q = p + (t * d);                                            // ray::at (ray.h:42-43)
       storeV3(P.spQ, P.cap, g, Q);
       storeV3(P.spN, P.cap, g, sf.N);
@@ -987,7 +993,7 @@ k_hit(DevScene S, int items, int par, RaySrc R, int level, int depthLeft, int bl
       } else {
         storeV3(P.rayI, P.cap, rayOff + i, V3(0.0, 0.0, 0.0));   // RayTracer.cpp:213-224 (k_background adds a cube map)
       }
-      if (level == 0) P.primaryId[i] = 0;
+      if (level == 0 && firstSampleOfPixel(R.fm, i)) P.primaryId[i] = 0;
       continue;
     }
     const size_t g = spOff + s;
@@ -1003,7 +1009,7 @@ k_hit(DevScene S, int items, int par, RaySrc R, int level, int depthLeft, int bl
     const V3 Q = ray.p + (P.hitT[i] * ray.d);                            // ray::at (ray.h:42-43)
     P.spRayGlobal[g] = (int)(rayOff + i);
     P.spMat[g] = (int)((unsigned int)(info & RT_FI_MATERIAL) | ((info & RT_FI_LIT) ? RT_SPM_LIT : 0u));   // material.cpp:50-53
-    if (level == 0) P.primaryId[i] = sf.objectID;
+    if (level == 0 && firstSampleOfPixel(R.fm, i)) P.primaryId[i] = sf.objectID;
     storeV3(P.spQ, P.cap, g, Q);
     storeV3(P.spN, P.cap, g, sf.N);
     int childRefl = -1;
@@ -1018,7 +1024,6 @@ k_hit(DevScene S, int items, int par, RaySrc R, int level, int depthLeft, int bl
         const V3 reflDir = normalized(cosVector + sinVector);
         P.rayParent[np][a] = (int)g;
         storeV3(P.rayD[np], P.cap, a, reflDir);
-        P.rayType[np][a] = RT_RAY_REFLECTION;
         childRefl = (int)(nextRayOff + a);
       }
     }
@@ -1696,7 +1701,11 @@ int renderBatch(RenderCtx& cx, long long first, int count, long long* slotsUsed,
     Pool P = pool;   // this level's view of the pool: its own counter block
     P.counters = pool.counters + level;
     RaySrc R;
-    R.parent = P.rayParent[par]; R.spQ = P.spQ; R.d = P.rayD[par]; R.type = P.rayType[par]; R.stride = P.cap;
+    // every hit a plain triangle and nothing refracts: k_hit does what k_classify,
+    // k_surface and k_shade otherwise share out, and its queues hold reflected rays only
+    const bool fused = sc->fusedHit && sc->hasFaces && !sc->surfaceRest && sc->dev.opaque;
+    R.parent = P.rayParent[par]; R.spQ = P.spQ; R.d = P.rayD[par]; R.type = fused ? nullptr : P.rayType[par];
+    R.stride = P.cap;
     R.primary = level == 0 ? 1 : 0;
     R.fm = cx.fm;
     R.first = makeSlotBase(cx.fm, first);
@@ -1713,7 +1722,6 @@ int renderBatch(RenderCtx& cx, long long first, int count, long long* slotsUsed,
     // k_classify, k_surface and k_shade otherwise share out
     // nothing to show behind a ray that hits nothing, and no coefficient that would turn a zero into a NaN
     const int blackMiss = (!(rp.use_cubemap && sc->dev.cube_w > 0) && sc->finiteCoefficients) ? 1 : 0;
-    const bool fused = sc->fusedHit && sc->hasFaces && !sc->surfaceRest && sc->dev.opaque;
     if (fused) {
       k_hit<<<tiles, kBlock, 0, sc->stream>>>(sc->dev, items, par, R, level, rp.depth - level, blackMiss, P);
     } else {
