@@ -101,6 +101,7 @@ struct Pool {
   double* spKd; double* spKs; double* spShin;
   double* spKr; double* spKt; double* spIor;
   int* primaryId;                                // objectID of the level-0 hit per sample
+  int* primarySp;                                // pool index of the level-0 shade point per sample, -1: no hit
   Counters* counters;
 };
 
@@ -487,9 +488,11 @@ k_classify(int items, int level, RaySrc R, int blackMiss, Pool P) {
       const bool isHit = (hitMask >> k) & 1u;
       const unsigned int s = tileSlot(ts, 0, k, isHit);
       if (i >= n) continue;
+      if (level == 0) P.primarySp[i] = (isHit && spOff + s < P.cap) ? (int)(spOff + s) : -1;
       if (!isHit) {
-        if (level > 0 && blackMiss) {
-          if (R.type[i] >= 0) dropChild(R, P.spChildRefl, P.spChildRefr, i);
+        if (blackMiss) {
+          // level 0: k_resolve paints a sample without a shade point black
+          if (level > 0 && R.type[i] >= 0) dropChild(R, P.spChildRefl, P.spChildRefr, i);
         } else {
           storeV3(P.rayI, P.cap, rayOff + i, V3(0.0, 0.0, 0.0));
         }
@@ -987,9 +990,11 @@ k_hit(DevScene S, int items, int par, RaySrc R, int level, int depthLeft, int bl
     const unsigned int s = tileSlot(tsHit, 0, k, hit);
     const unsigned int a = tileSlot(tsRefl, 0, k, refl);
     if (i >= n) continue;
+    if (level == 0) P.primarySp[i] = (hit && spOff + s < P.cap) ? (int)(spOff + s) : -1;
     if (!hit) {
-      if (level > 0 && blackMiss) {
-        P.spChildRefl[R.parent[i]] = -1;   // see dropChild; every ray of such a scene is a reflected one
+      if (blackMiss) {
+        // level 0: k_resolve paints a sample without a shade point black
+        if (level > 0) P.spChildRefl[R.parent[i]] = -1;   // see dropChild; every ray of such a scene is a reflected one
       } else {
         storeV3(P.rayI, P.cap, rayOff + i, V3(0.0, 0.0, 0.0));   // RayTracer.cpp:213-224 (k_background adds a cube map)
       }
@@ -1007,7 +1012,7 @@ k_hit(DevScene S, int items, int par, RaySrc R, int level, int depthLeft, int bl
     Surface sf;
     surfaceNormalOfFace(S, fi, info, ray.p, ray.d, sf);
     const V3 Q = ray.p + (P.hitT[i] * ray.d);                            // ray::at (ray.h:42-43)
-    P.spRayGlobal[g] = (int)(rayOff + i);
+    if (level > 0) P.spRayGlobal[g] = (int)(rayOff + i);   // for k_combine, which level 0 does not go through
     P.spMat[g] = (int)((unsigned int)(info & RT_FI_MATERIAL) | ((info & RT_FI_LIT) ? RT_SPM_LIT : 0u));   // material.cpp:50-53
     if (level == 0 && firstSampleOfPixel(R.fm, i)) P.primaryId[i] = sf.objectID;
     storeV3(P.spQ, P.cap, g, Q);
@@ -1031,7 +1036,25 @@ k_hit(DevScene S, int items, int par, RaySrc R, int level, int depthLeft, int bl
   }
 }
 
-// intensity = shade; += kr*traceRay(reflected); += kt*traceRay(refracted)
+// What traceRay returns for the ray that made shade point g, once the colours of
+// its child rays are known: intensity = shade; += kr*traceRay(reflected);
+// += kt*traceRay(refracted) (RayTracer.cpp:150-201).
+__device__ __forceinline__ V3 combinedColour(const DevScene& S, const Pool& P, size_t g) {
+  V3 I = loadV3(P.spShade, P.cap, g);
+  const int cr = P.spChildRefl[g], ct = S.opaque ? -1 : P.spChildRefr[g];
+  if (cr >= 0 || ct >= 0) {
+    const unsigned int mw = (unsigned int)P.spMat[g];
+    const bool interp = (mw & RT_SPM_INTERP) != 0;
+    const DevMat* dm = interp ? nullptr : &S.devMats[mw & RT_SPM_INDEX];
+    if (cr >= 0) I = I + prod(interp ? loadV3(P.spKr, P.cap, g) : V3(dm->kr), loadV3(P.rayI, P.cap, (size_t)cr));
+    if (ct >= 0) I = I + prod(interp ? loadV3(P.spKt, P.cap, g) : V3(dm->kt), loadV3(P.rayI, P.cap, (size_t)ct));
+  }
+  return I;
+}
+
+// Levels 1 and deeper, bottom-up: the colour of every ray that hit something,
+// into the ray's slot, where the level above finds it.  (Level 0 needs no such
+// pass: k_resolve works a primary sample's colour out where it uses it.)
 // (P.counters: the block of the level that is being combined)
 __global__ void __launch_bounds__(kBlock)
 k_combine(DevScene S, Pool P) {
@@ -1040,16 +1063,7 @@ k_combine(DevScene S, Pool P) {
   const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (s < nsp) {
     const size_t g = (size_t)P.counters->spOff + s;
-    V3 I = loadV3(P.spShade, P.cap, g);
-    const int cr = P.spChildRefl[g], ct = S.opaque ? -1 : P.spChildRefr[g];
-    if (cr >= 0 || ct >= 0) {
-      const unsigned int mw = (unsigned int)P.spMat[g];
-      const bool interp = (mw & RT_SPM_INTERP) != 0;
-      const DevMat* dm = interp ? nullptr : &S.devMats[mw & RT_SPM_INDEX];
-      if (cr >= 0) I = I + prod(interp ? loadV3(P.spKr, P.cap, g) : V3(dm->kr), loadV3(P.rayI, P.cap, (size_t)cr));
-      if (ct >= 0) I = I + prod(interp ? loadV3(P.spKt, P.cap, g) : V3(dm->kt), loadV3(P.rayI, P.cap, (size_t)ct));
-    }
-    storeV3(P.rayI, P.cap, (size_t)P.spRayGlobal[g], I);
+    storeV3(P.rayI, P.cap, (size_t)P.spRayGlobal[g], combinedColour(S, P, g));
   }
 }
 
@@ -1065,8 +1079,8 @@ k_combine(DevScene S, Pool P) {
 constexpr int kResolveSamples = 1024;   // LDS rows * pitch per colour channel
 
 __global__ void __launch_bounds__(kBlock)
-k_resolve(FrameMap fm, SlotBase first, int nPixels, int ppb, Pool P, unsigned char* rgb, int* hitId,
-          const long long* tileOffset) {
+k_resolve(DevScene S, FrameMap fm, SlotBase first, int nPixels, int ppb, int blackMiss, Pool P, unsigned char* rgb,
+          int* hitId, const long long* tileOffset) {
   __shared__ double lds[3][kResolveSamples + kBlock];
   __shared__ int ldsId[kBlock];
   const int ns = fm.ns, pitch = ns | 1;
@@ -1074,7 +1088,10 @@ k_resolve(FrameMap fm, SlotBase first, int nPixels, int ppb, Pool P, unsigned ch
   const int npix = min(ppb, nPixels - pix0);
   const size_t base = (size_t)pix0 * ns;
   for (int e = threadIdx.x; e < npix * ns; e += kBlock) {
-    V3 c = loadV3(P.rayI, P.cap, base + e);
+    // the sample's colour: that of its level-0 shade point, or the background's
+    // (black, or what k_background left in the ray's slot)
+    const int sp = P.primarySp[base + e];
+    V3 c = sp >= 0 ? combinedColour(S, P, (size_t)sp) : blackMiss ? V3(0.0, 0.0, 0.0) : loadV3(P.rayI, P.cap, base + e);
     if (c.x < 0) c.x = 0.0;
     if (c.x > 1) c.x = 1.0;
     if (c.y < 0) c.y = 0.0;
@@ -1496,6 +1513,7 @@ int ensurePool(RtScene* sc, size_t cap) {
   POOL_ALLOC(P.spChildRefr, int, cap);
   POOL_ALLOC(P.spRayGlobal, int, cap);
   POOL_ALLOC(P.primaryId, int, cap);
+  POOL_ALLOC(P.primarySp, int, cap);
   POOL_ALLOC(P.spKd, double, 3 * icap);
   POOL_ALLOC(P.spKs, double, 3 * icap);
   POOL_ALLOC(P.spShin, double, icap);
@@ -1511,7 +1529,7 @@ int ensurePool(RtScene* sc, size_t cap) {
 
 size_t poolBytesPerSlot(int nLights, bool interp, bool opaque) {
   const size_t nl = (size_t)std::max(1, nLights);
-  return 2 * (24 + 4 + 4) + 12 + 24 * 2 + 24 * 2 + 4 * 5 + nl * (opaque ? 4 : 12) + (interp ? 24 * 4 + 8 * 2 : 0);
+  return 2 * (24 + 4 + 4) + 12 + 24 * 2 + 24 * 2 + 4 * 6 + nl * (opaque ? 4 : 12) + (interp ? 24 * 4 + 8 * 2 : 0);
 }
 
 struct TileLayout {
@@ -1759,7 +1777,7 @@ int renderBatch(RenderCtx& cx, long long first, int count, long long* slotsUsed,
   }
   // the colours of every level's shade points are needed from here on
   if (sidePending) HIP_TRY(hipStreamWaitEvent(sc->stream, sc->evSide, 0));
-  for (int level = levelsRun - 1; level >= 0; level--) {
+  for (int level = levelsRun - 1; level >= 1; level--) {   // (level 0: in k_resolve)
     Pool P = pool;
     P.counters = pool.counters + level;
     k_combine<<<blocksFor((long long)sc->levelN[(size_t)level], kBlock), kBlock, 0, sc->stream>>>(sc->dev, P);
@@ -1767,8 +1785,9 @@ int renderBatch(RenderCtx& cx, long long first, int count, long long* slotsUsed,
   {
     const int pitch = ns | 1;
     const int ppb = std::max(1, std::min(kBlock, kResolveSamples / pitch));
-    k_resolve<<<(count + ppb - 1) / ppb, kBlock, 0, sc->stream>>>(cx.fm, makeSlotBase(cx.fm, first), count, ppb, pool, cx.rgbDev,
-                                                                    cx.hitDev, cx.tileOffDev);
+    const int blackMiss = (!(rp.use_cubemap && sc->dev.cube_w > 0) && sc->finiteCoefficients) ? 1 : 0;
+    k_resolve<<<(count + ppb - 1) / ppb, kBlock, 0, sc->stream>>>(sc->dev, cx.fm, makeSlotBase(cx.fm, first), count, ppb, blackMiss,
+                                                                    pool, cx.rgbDev, cx.hitDev, cx.tileOffDev);
   }
   HIP_TRY(hipGetLastError());
   // the batch's one read-back: every level's counter block, and the block the
