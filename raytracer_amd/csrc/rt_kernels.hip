@@ -624,7 +624,8 @@ __device__ __forceinline__ void shadowQuery(const DevScene& S, const RtLight& l,
   const double lightDistance = length2(position - Q);
   // FAST: an occluder beyond the light is irrelevant; bound the search a little
   // past the light so that the strict < of the caller decides
-  const double limit = sqrt(lightDistance) * 1.0000001 + 1e-7;
+  // (only ever a cull bound: a binary32 square root, widened past its rounding, will do)
+  const double limit = (double)(sqrtf((float)lightDistance) * 1.000001f) + 1e-7;
   if (FAST && S.opaque) {
     // Every material has kt == 0, so the filter colour of ANY occluder in
     // front of the light is the closest occluder's: stop at the first one.

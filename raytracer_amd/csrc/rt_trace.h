@@ -844,8 +844,13 @@ typedef int rt_i4 __attribute__((ext_vector_type(4)));
 // conversion -- and each plane distance is one multiply-add plane * inv - p *
 // inv, widened by the ray's error bound: |plane| <= bvhErrG, so the bound of
 // bvhRaySetup covers the roundings of this form as well.
+// RAW: tn[c] is the entry distance whether the child is hit or not and hit[c]
+// says which it is (what the ordered descent of a closest-hit query wants);
+// otherwise tn[c] is +inf for a child that is not hit and hit[] is not written.
+template <bool RAW>
 __device__ __forceinline__ void bvhNodeSlabsUniform(const DevScene& S, const BvhRay& r, int ref, unsigned int negMask,
-                                                    unsigned int copy, float bestTf, float tn[4], int kid[4]) {
+                                                    unsigned int copy, float bestTf, float tn[4], int kid[4],
+                                                    bool hit[4]) {
   const float kInf = __int_as_float(0x7f800000);
   // eight copies of every node, one per combination of direction signs, each
   // with its children listed near to far for directions of those signs
@@ -894,8 +899,13 @@ __device__ __forceinline__ void bvhNodeSlabsUniform(const DevScene& S, const Bvh
     const float tfar1 = fminf(fminf(fminf(fx.y, fy.y), fz.y), bestTf);
     const bool h0 = (tnear0 <= tfar0) & (tfar0 >= 0.0f);
     const bool h1 = (tnear1 <= tfar1) & (tfar1 >= 0.0f);
-    tn[c] = h0 ? tnear0 : kInf;
-    tn[c + 1] = h1 ? tnear1 : kInf;
+    if (RAW) {
+      tn[c] = tnear0; tn[c + 1] = tnear1;
+      hit[c] = h0; hit[c + 1] = h1;
+    } else {
+      tn[c] = h0 ? tnear0 : kInf;
+      tn[c + 1] = h1 ? tnear1 : kInf;
+    }
   }
 }
 
@@ -1129,7 +1139,8 @@ __device__ int traceBvh(const DevScene& S, const V3& p, const V3& d, int rayType
       // push vector registers over an occupancy step.)
       const int uref = __builtin_amdgcn_readfirstlane(ref);
       if (TRI && !ANYHIT && uniformOk && __ballot(ref != uref) == 0) {
-        bvhNodeSlabsUniform(S, r, uref, negMask, negMask, bestTf, tn, kid);
+        bool hk[4];
+        bvhNodeSlabsUniform<true>(S, r, uref, negMask, negMask, bestTf, tn, kid, hk);
         // The children of this copy of the node come near to far for rays of
         // these direction signs (by box centre along the signs' diagonal, fixed
         // when the scene was created): the first one hit is next, the others go
@@ -1137,7 +1148,7 @@ __device__ int traceBvh(const DevScene& S, const V3& p, const V3& d, int rayType
         // references stay in scalar registers.  The order is only nearly the
         // order of entry distances; a closer hit found late still culls what was
         // pushed before it (pop), so the result does not depend on it.
-        const bool h0 = tn[0] < kInf, h1 = tn[1] < kInf, h2 = tn[2] < kInf, h3 = tn[3] < kInf;
+        const bool h0 = hk[0], h1 = hk[1], h2 = hk[2], h3 = hk[3];
         if (h3 & (h0 | h1 | h2)) RT_BVH_PUSH(kid[3], tn[3])
         if (h2 & (h0 | h1)) RT_BVH_PUSH(kid[2], tn[2])
         if (h1 & h0) RT_BVH_PUSH(kid[1], tn[1])
@@ -1152,7 +1163,7 @@ __device__ int traceBvh(const DevScene& S, const V3& p, const V3& d, int rayType
       // (occlusion queries visit every overlapped subtree whatever the order:
       // they all read copy 0 and pick the nearest child as below)
       // (measured: taking the first overlapped child instead costs 8 %)
-      if (TRI && ANYHIT && uniformOk && __ballot(ref != uref) == 0) bvhNodeSlabsUniform(S, r, uref, negMask, 0u, bestTf, tn, kid);
+      if (TRI && ANYHIT && uniformOk && __ballot(ref != uref) == 0) bvhNodeSlabsUniform<false>(S, r, uref, negMask, 0u, bestTf, tn, kid, nullptr);
       else
 #endif
       bvhNodeSlabs(S, p, r, ref, bestTf, tn, kid);
