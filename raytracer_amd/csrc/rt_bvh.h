@@ -242,6 +242,10 @@ constexpr int32_t kEmptyChild = 0x7fffffff;
 class Collapser {
  public:
   std::vector<Node4> nodes;
+  // The child boxes of every 4-wide node before quantisation (binary32, rounded
+  // outward by the binary builder): lo[a][c] / hi[a][c]; an unused slot is inverted.
+  struct Tight { float lo[3][4], hi[3][4]; };
+  std::vector<Tight> tight;
   int maxDepth = 0;
 
   void run(const std::vector<Node>& bin) {
@@ -249,6 +253,9 @@ class Collapser {
     nodes.clear();
     nodes.reserve(bin.size() / 2 + 1);
     nodes.emplace_back();
+    tight.clear();
+    tight.reserve(bin.size() / 2 + 1);
+    tight.emplace_back();
     maxDepth = 0;
     // explicit work list instead of recursion: (binary node, output slot, depth)
     struct Job { int binNode; int out; int depth; };
@@ -282,6 +289,7 @@ class Collapser {
       }
       Node4 out;
       std::memset(&out, 0, sizeof out);
+      Tight tb;
       Box all; all.reset();
       for (const Kid& k : kids) all.grow(k.box);
       int exps[3];
@@ -303,9 +311,11 @@ class Collapser {
         if (c >= (int)kids.size()) {
           out.child[c] = kEmptyChild;
           for (int a = 0; a < 3; a++) out.qlo[a] |= 255u << (8 * c);   // inverted box: upper planes stay 0
+          for (int a = 0; a < 3; a++) { tb.lo[a][c] = 1.0f; tb.hi[a][c] = 0.0f; }
           continue;
         }
         const Kid& k = kids[c];
+        for (int a = 0; a < 3; a++) { tb.lo[a][c] = down(k.box.lo[a]); tb.hi[a][c] = up(k.box.hi[a]); }
         for (int a = 0; a < 3; a++) {
           const double sc = std::ldexp(1.0, exps[a]);
           double ql = std::floor((k.box.lo[a] - (double)out.origin[a]) / sc);
@@ -318,6 +328,7 @@ class Collapser {
         if (k.ref >= 0) {
           const int idx = (int)nodes.size();
           nodes.emplace_back();
+          tight.emplace_back();
           out.child[c] = idx;
           jobs.push_back({k.ref, idx, j.depth + 1});
         } else {
@@ -325,6 +336,7 @@ class Collapser {
         }
       }
       nodes[j.out] = out;
+      tight[j.out] = tb;
     }
   }
 

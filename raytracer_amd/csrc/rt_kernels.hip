@@ -2225,14 +2225,12 @@ int rt_scene_create(const RtSceneDesc* d, RtScene** out) {
         std::vector<DevBvhNodeF> fn(wide.nodes.size() * 8);
         for (size_t i = 0; i < wide.nodes.size(); i++) {
           const rtbvh::Node4& n4 = wide.nodes[i];
-          const double sc[3] = {n4.scaleX, n4.scaleY, n4.scaleZ};
+          // (the boxes as the builder made them, not their 8-bit quantised form:
+          // this path has room for them, and tighter boxes cull more)
+          const rtbvh::Collapser::Tight& tb = wide.tight[i];
           float blo[3][4], bhi[3][4];
           for (int c = 0; c < 4; c++)
-            for (int a = 0; a < 3; a++) {
-              const double ql = (double)((n4.qlo[a] >> (8 * c)) & 255u), qh = (double)((n4.qhi[a] >> (8 * c)) & 255u);
-              blo[a][c] = rtbvh::down((double)n4.origin[a] + ql * sc[a]);
-              bhi[a][c] = rtbvh::up((double)n4.origin[a] + qh * sc[a]);
-            }
+            for (int a = 0; a < 3; a++) { blo[a][c] = tb.lo[a][c]; bhi[a][c] = tb.hi[a][c]; }
           for (int o = 0; o < 8; o++) {
             double key[4];
             int order[4] = {0, 1, 2, 3};
@@ -2262,6 +2260,8 @@ int rt_scene_create(const RtSceneDesc* d, RtScene** out) {
         HIP_TRY(upload(fn.data(), fn.size(), &fp));
         keep(fp);
         D.bvhF = fp;
+        D.bvhLaneF = fn.size() * sizeof(DevBvhNodeF) < (size_t)0x7fffffff ? 1 : 0;
+        if (const char* e = std::getenv("RT_AMD_LANE_F32")) { if (std::atoi(e) == 0) D.bvhLaneF = 0; }
       }
       for (int a = 0; a < 3; a++) {
         D.bvh_bb_min[a] = bvh.rootBox.lo[a];
