@@ -223,7 +223,9 @@ void rt_scene_destroy(RtScene* scene);
 int rt_render(RtScene* scene, const RtRenderParams* params,
               unsigned char* rgb8_out, int* hit_id_out, RtStats* stats);
 
-/* Scene::intersect for n rays given as 6 doubles (p, d) each. Host pointers. */
+/* Scene::intersect for n rays given as 6 doubles (p, d) each. Host pointers.
+ * Stages through a device buffer kept in the scene handle, which grows (one
+ * hipMalloc) when a call brings more rays than any before it. */
 int rt_intersect_batch(RtScene* scene, int traversal, int n, const double* rays_pd,
                        const int* ray_types, RtHit* hits);
 
@@ -231,8 +233,8 @@ int rt_intersect_batch(RtScene* scene, int traversal, int n, const double* rays_
  * HIP graph capture, tight serving loops, harnesses that forbid it).  It has no
  * counterpart in the reference.  Same arguments and results as
  * rt_intersect_batch, but rays, types and hit records are staged in an array
- * that is part of the library's code object instead of per-call hipMalloc'ed
- * buffers: the call allocates and frees nothing.  At most 65536 rays per call
+ * that is part of the library's code object instead of a buffer the handle
+ * may have to grow: the call allocates and frees nothing.  At most 65536 rays per call
  * (more: RT_ERR_INVALID).  Every GPU the library runs on holds its own copy of
  * the array (7.25 MiB) until the process ends; all calls on one GPU share it,
  * so calls that overlap on one GPU -- from different threads or scenes -- race. */

@@ -1387,6 +1387,7 @@ struct RtScene {
   int growthDepth = -1;
   unsigned char* frameRgb = nullptr; int* frameHit = nullptr; size_t framePixels = 0;
   double* jitterDev = nullptr; size_t jitterCap = 0;
+  unsigned char* isectBuf = nullptr; size_t isectCap = 0;   // rt_intersect_batch's staging, in rays
   std::vector<hipEvent_t> events;  // pairs around traversal kernels
   size_t eventsUsed = 0;
   std::vector<unsigned char> eventKind;   // per pair: 0 k_trace, 1 k_lights
@@ -1413,6 +1414,7 @@ struct RtScene {
     if (frameRgb) hipFree(frameRgb);
     if (frameHit) hipFree(frameHit);
     if (jitterDev) hipFree(jitterDev);
+    if (isectBuf) hipFree(isectBuf);
     for (hipEvent_t e : events) hipEventDestroy(e);
     if (countersHost) hipHostFree(countersHost);
     if (evStart) hipEventDestroy(evStart);
@@ -2655,18 +2657,33 @@ int rt_intersect_batch(RtScene* sc, int traversal, int n, const double* rays_pd,
   if (!sc || n < 0 || (n > 0 && (!rays_pd || !hits))) return fail(RT_ERR_INVALID, "bad argument");
   if (n == 0) return RT_OK;
   HIP_TRY(hipSetDevice(sc->device));
-  DevBuf rays, types, hitBuf;
-  HIP_TRY(rays.allocCopy(rays_pd, 6 * (size_t)n * sizeof(double)));
-  if (ray_types) HIP_TRY(types.allocCopy(ray_types, (size_t)n * sizeof(int)));
-  HIP_TRY(hitBuf.alloc((size_t)n * sizeof(RtHit)));
+  // staging for rays, hit records and ray types: kept in the handle, grown when a call needs more
+  if ((size_t)n > sc->isectCap) {
+    if (sc->isectBuf) (void)hipFree(sc->isectBuf);
+    sc->isectBuf = nullptr;
+    sc->isectCap = 0;
+    const size_t cap = std::max<size_t>((size_t)n + (size_t)n / 2, 4096);
+    const hipError_t e = hipMalloc((void**)&sc->isectBuf, cap * (6 * sizeof(double) + sizeof(RtHit) + sizeof(int)));
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      return fail(e == hipErrorOutOfMemory ? RT_ERR_NOMEM : RT_ERR_DEVICE, "cannot allocate the ray staging buffer");
+    }
+    sc->isectCap = cap;
+  }
+  double* raysDev = reinterpret_cast<double*>(sc->isectBuf);
+  RtHit* hitsDev = reinterpret_cast<RtHit*>(sc->isectBuf + sc->isectCap * 6 * sizeof(double));
+  int* typesDev = reinterpret_cast<int*>(sc->isectBuf + sc->isectCap * (6 * sizeof(double) + sizeof(RtHit)));
+  HIP_TRY(hipMemcpyAsync(raysDev, rays_pd, 6 * (size_t)n * sizeof(double), hipMemcpyHostToDevice, sc->stream));
+  if (ray_types) HIP_TRY(hipMemcpyAsync(typesDev, ray_types, (size_t)n * sizeof(int), hipMemcpyHostToDevice, sc->stream));
+  const int* typesArg = ray_types ? typesDev : nullptr;
   if (traversal == RT_TRAVERSE_FAST)
     k_intersect<true><<<gridFor(n), kBlock, (size_t)RT_LDS_STACK_BYTES_CLOSEST * kBlock, sc->stream>>>(
-        sc->dev, n, rays.as<double>(), types.as<int>(), hitBuf.as<RtHit>());
+        sc->dev, n, raysDev, typesArg, hitsDev);
   else
     k_intersect<false><<<gridFor(n), kBlock, (size_t)RT_KD_LDS_STACK_BYTES * kBlock, sc->stream>>>(
-        sc->dev, n, rays.as<double>(), types.as<int>(), hitBuf.as<RtHit>());
+        sc->dev, n, raysDev, typesArg, hitsDev);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpyAsync(hits, hitBuf.p, (size_t)n * sizeof(RtHit), hipMemcpyDeviceToHost, sc->stream));
+  HIP_TRY(hipMemcpyAsync(hits, hitsDev, (size_t)n * sizeof(RtHit), hipMemcpyDeviceToHost, sc->stream));
   HIP_TRY(hipStreamSynchronize(sc->stream));
   return RT_OK;
 }
