@@ -7,26 +7,31 @@
 //   level L = 0 .. depth                              (main stream)
 //     k_trace     closest hit of every ray of the level (Scene::intersect);
 //                 level 0 generates its camera rays in place
-//     k_classify  misses -> black background; hits -> compacted shade-point slots
-//     k_surface   shade point of a triangle: Q, N, material word
-//                 (k_surface_rest: other primitives and interpolated materials;
-//                 k_background: cube map for the misses)
-//     k_shade     the reflected / refracted rays of the next level, compacted
-//                 into the next level's queue
+//     k_hit       hits -> compacted shade-point slots with Q, N and the material
+//                 word; their reflected rays, compacted, into the next level's
+//                 queue; a secondary ray that hits nothing is struck from its
+//                 parent (scenes of plain triangles in which nothing transmits)
+//       or k_classify (the compaction), k_surface / k_surface_rest (the shade
+//       point: triangles / other primitives and interpolated materials) and
+//       k_shade (reflected and refracted rays) for every other scene
+//     k_background  cube map for the rays that hit nothing, where one is shown
+//     k_advance   hands the level's counts on to the next level, on the device
 //                                                     (side stream, beside the
 //                                                      main stream's next level)
 //     k_shadow    one thread per (light, shade point): the shadow query
 //     k_lights    Material::shade: Light::{distance,shadow}Attenuation from the
 //                 query's outcome and the Phong terms, summed in light order
-//   level L = depth .. 0
+//   level L = depth .. 1
 //     k_combine   I = shade + kr*I(reflected) + kt*I(refracted), i.e. the
-//                 additions of traceRay in the reference's order
-//   k_resolve     clamp, mean over sub-samples, truncate to RGB8
+//                 additions of traceRay in the reference's order, into the ray's slot
+//   k_resolve     the same sum for the level-0 shade point of every sample, clamp,
+//                 mean over sub-samples, truncate to RGB8
 //
 // Every ray of a batch owns one slot of a pool; a shade point stores the pool
 // slots of its two children, so the bottom-up pass reproduces the recursion's
 // floating-point evaluation order exactly and is independent of the order in
-// which waves appended to the queues.
+// which waves appended to the queues.  The host queues a whole batch -- every
+// level, the bottom-up pass, the resolve -- and waits once (renderBatch).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
