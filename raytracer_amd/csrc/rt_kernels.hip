@@ -1441,9 +1441,10 @@ namespace {
 // v = n + delta with n a non-negative integer below 2^20 and |delta| <= 1e-12:
 // what powNearInt takes for an exponent.
 bool nearSmallInt(double v, int& n, double& delta) {
-  if (!(v >= -1.0e-12 && v < 1048576.0)) return false;
+  if (!(v >= 0.0 && v < 1048576.0)) return false;
   const double r = std::floor(v + 0.5);
   if (std::fabs(v - r) > 1.0e-12) return false;
+  if (r == 0.0 && v != 0.0) return false;   // a positive exponent, however small, sends 0 to 0 and not to 1
   n = (int)r;
   delta = v - r;
   return true;
