@@ -24,6 +24,8 @@ pytestmark = pytest.mark.gpu
 KINDS = ("sphere", "box", "cylinder", "cone", "square")
 # RT_FUZZ_SEEDS=N widens both tests to N seeds each for a longer hunt
 N_SEEDS = int(os.environ.get("RT_FUZZ_SEEDS", "0"))
+# RT_FUZZ_FIRST=K starts the widened ranges at seed K (another stretch of seeds per hunt)
+FIRST = int(os.environ.get("RT_FUZZ_FIRST", "0")) if N_SEEDS > 0 else 0
 
 
 def _rand_material(rng):
@@ -90,7 +92,7 @@ def _counts(st):
     return (st.rays_primary, st.rays_reflect, st.rays_refract, st.rays_shadow, st.shade_points)
 
 
-@pytest.mark.parametrize("seed", range(max(10, N_SEEDS)))
+@pytest.mark.parametrize("seed", range(FIRST, FIRST + max(10, N_SEEDS)))
 def test_random_scene(built, seed):
     text, opts = random_scene(seed)
     w, h, depth = 112, 84, 3
@@ -111,7 +113,7 @@ def test_random_scene(built, seed):
     assert _counts(fst) == _counts(ls)
 
 
-@pytest.mark.parametrize("seed", range(10, max(22, 10 + N_SEEDS)))
+@pytest.mark.parametrize("seed", range(FIRST + 10, FIRST + max(22, 10 + N_SEEDS)))
 def test_random_scene_cubemap_antialias_deep(built, seed):
     """The same generator with a cube map behind the scene, 2x2 or 3x3 jittered
     samples per pixel and recursion depth 4 or 5."""
@@ -172,7 +174,7 @@ def random_mesh_scene(seed):
     return s, opts
 
 
-@pytest.mark.parametrize("seed", range(max(10, N_SEEDS)))
+@pytest.mark.parametrize("seed", range(FIRST, FIRST + max(10, N_SEEDS)))
 def test_random_mesh_only_scene_in_small_batches_and_shards(built, seed):
     """Triangle-only scenes, rendered in several small batches (so that the level
     pipeline of one batch runs into the next) and as three tile shards that are
@@ -218,7 +220,7 @@ def _same(a, b):
     return (a == b) | (np.isnan(a) & np.isnan(b))
 
 
-@pytest.mark.parametrize("seed", range(max(6, N_SEEDS // 4)))
+@pytest.mark.parametrize("seed", range(FIRST, FIRST + max(6, N_SEEDS // 4)))
 def test_random_rays_on_random_scenes_bit_exact(built, seed):
     """Scene::intersect on 3000 rays per scene -- random, axis-parallel, starting
     on and inside objects, with NaN directions and NaN origins, of every ray type:
