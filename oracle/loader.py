@@ -18,6 +18,8 @@ _SYMBOLS = {
                              C.c_void_p, C.POINTER(abi.RtStats), C.c_int]),
     "orc_render_pixels": (C.c_int, [C.POINTER(abi.RtSceneDesc), C.POINTER(abi.RtRenderParams), C.c_int,
                                     abi.PI, C.c_void_p, C.POINTER(abi.RtStats), C.c_int]),
+    "orc_primary_ids": (C.c_int, [C.POINTER(abi.RtSceneDesc), C.POINTER(abi.RtRenderParams), C.c_int,
+                                  abi.PI, abi.PI, C.c_int]),
     "orc_intersect_batch": (C.c_int, [C.POINTER(abi.RtSceneDesc), C.c_int, abi.PD, abi.PI,
                                       C.POINTER(abi.RtHit)]),
     "orc_edge_mask": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
@@ -56,6 +58,17 @@ def render_pixels(desc_ptr, params, xy, threads=1):
     if rc != 0:
         raise RuntimeError("orc_render_pixels failed: %d" % rc)
     return out, st
+
+
+def primary_ids(desc_ptr, params, xy, threads=1):
+    """Geometry::objectID seen by the first sample of each listed pixel (0: nothing)."""
+    xy = np.ascontiguousarray(xy, dtype=np.int32).reshape(-1, 2)
+    ids = np.zeros(len(xy), dtype=np.int32)
+    rc = lib().orc_primary_ids(desc_ptr, C.byref(params), len(xy), xy.ctypes.data_as(abi.PI),
+                               ids.ctypes.data_as(abi.PI), threads)
+    if rc != 0:
+        raise RuntimeError("orc_primary_ids failed: %d" % rc)
+    return ids
 
 
 def intersect_batch(desc_ptr, rays_pd, types=None):

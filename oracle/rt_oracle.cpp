@@ -941,6 +941,41 @@ int orc_render_pixels(const RtSceneDesc* d, const RtRenderParams* p, int n, cons
   return RT_OK;
 }
 
+// Geometry::objectID of what the FIRST sample of each listed pixel sees (0: nothing):
+// the value tracePixel / tracePixelAntiAlias's first trace() call finds in
+// Scene::intersect (src/RayTracer.cpp:45-62,84-93; src/scene/scene.cpp:133-159).
+// One closest-hit query per pixel, no shading: cheap enough to hold a frame's
+// primary-hit map against the oracle on 10^5 pixels.
+int orc_primary_ids(const RtSceneDesc* d, const RtRenderParams* p, int n, const int* xy, int* ids,
+                    int nThreads) {
+  if (!d || !p || n < 0 || (n > 0 && (!xy || !ids))) return RT_ERR_INVALID;
+  if (nThreads < 1) nThreads = 1;
+  const bool aa = p->aa_mode == RT_AA_FULL;
+  runThreads(d, p, nThreads, [&](int t, Tracer& tr) {
+    for (int k = t; k < n; k += nThreads) {
+      double x = double(xy[2 * k]) / double(p->width);
+      double y = double(xy[2 * k + 1]) / double(p->height);
+      if (aa) {
+        // sample (column 0, row 0) of tracePixelAntiAlias
+        const int ns = p->aa_samples;
+        double deltaX = (1.0 / double(p->width)) / ns;
+        double deltaY = (1.0 / double(p->height)) / ns;
+        double jx = p->jitter ? p->jitter[0] : 0.0, jy = p->jitter ? p->jitter[1] : 0.0;
+        x = x + 0 * deltaX + jx * deltaX;
+        y = y + 0 * deltaY + jy * deltaY;
+      }
+      x -= 0.5;
+      y -= 0.5;
+      V3 dir = V3(tr.S.look) + x * V3(tr.S.u) + y * V3(tr.S.v);
+      normalize(dir);
+      Ray r{V3(tr.S.eye), dir, RT_RAY_VISIBILITY};
+      Isect i;
+      ids[k] = tr.intersect(r, i) ? i.objectID : 0;
+    }
+  });
+  return RT_OK;
+}
+
 int orc_intersect_batch(const RtSceneDesc* d, int n, const double* raysPd, const int* types,
                         RtHit* hits) {
   if (!d || n < 0) return RT_ERR_INVALID;

@@ -129,6 +129,15 @@ __device__ __forceinline__ void checkCoverage(Counters* c, long long covered, lo
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && covered < items) c->overflow = RT_OVERFLOW_GRID;
 }
 
+// Rays of the level whose closest hit k_trace has written: all of them, unless
+// its grid (`traced` threads, sized from an estimate) fell short of the level.
+// The kernels that read hitPrim / hitT stop there: what lies beyond was never
+// written for this level (the batch is redone anyway, k_trace has flagged it).
+__device__ __forceinline__ long long tracedRays(const Counters* c, long long traced) {
+  const long long n = c->n;
+  return n < traced ? n : traced;
+}
+
 // Division of a 31-bit unsigned number by a divisor that is fixed for a launch
 // (tile size, tiles per row, samples per pixel): one multiply-high and a shift
 // instead of the few dozen instructions of a run-time division -- the sample ->
@@ -471,9 +480,9 @@ __device__ __forceinline__ unsigned int tileSlot(const TileScan& ts, int cls, in
 // added by k_background); hits get a shade-point slot (tile compaction) and are
 // handed to the surface kernels as RT_SPM_PENDING.
 __global__ void __launch_bounds__(kBlock)
-k_classify(int items, int level, RaySrc R, int blackMiss, Pool P) {
+k_classify(int items, int level, RaySrc R, int blackMiss, long long traced, Pool P) {
   __shared__ TileScan ts;
-  const long long n = P.counters->n;
+  const long long n = tracedRays(P.counters, traced);
   const size_t rayOff = P.counters->rayOff, spOff = P.counters->spOff;
   const long long perTile = (long long)kBlock * items;
   checkCoverage(P.counters, gridDim.x * perTile, n);
@@ -599,8 +608,8 @@ k_surface_rest(DevScene S, RaySrc R, int level, Pool P) {
 
 // Cube-map background of the rays that hit nothing (RayTracer.cpp:213-224).
 __global__ void __launch_bounds__(kBlock)
-k_background(DevScene S, RaySrc R, int filterWidth, Pool P) {
-  const long long n = P.counters->n;
+k_background(DevScene S, RaySrc R, int filterWidth, long long traced, Pool P) {
+  const long long n = tracedRays(P.counters, traced);
   checkCoverage(P.counters, (long long)gridDim.x * blockDim.x, n);
   const size_t rayOff = P.counters->rayOff;
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -816,9 +825,10 @@ __device__ __forceinline__ void shadePoint(const DevScene& S, const Pool& P, int
 // material is interpolated: powNearInt instead of pow.
 template <bool INTPOW>
 __global__ void __launch_bounds__(kBlock)
-k_lights(DevScene S, Pool P) {
-  const long long nsp = shadePointsOf(P);
+k_lights(DevScene S, long long queried, Pool P) {
+  long long nsp = shadePointsOf(P);
   checkCoverage(P.counters, (long long)gridDim.x * blockDim.x, nsp);
+  if (nsp > queried) nsp = queried;   // k_shadow's grid fell short (it has flagged the level): no outcomes beyond
   const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= nsp) return;
   const size_t g = (size_t)P.counters->spOff + s;
@@ -951,10 +961,10 @@ k_shade(DevScene S, int items, int par, RaySrc R, int depthLeft, Pool P) {
 #define RT_HIT_WAVES 5
 #endif
 __global__ void __launch_bounds__(kBlock, RT_HIT_WAVES)
-k_hit(DevScene S, int items, int par, RaySrc R, int level, int depthLeft, int blackMiss, Pool P) {
+k_hit(DevScene S, int items, int par, RaySrc R, int level, int depthLeft, int blackMiss, long long traced, Pool P) {
   __shared__ TileScan tsHit, tsRefl;
   __shared__ unsigned int litCount;
-  const long long n = P.counters->n;
+  const long long n = tracedRays(P.counters, traced);
   const size_t rayOff = P.counters->rayOff, spOff = P.counters->spOff;
   const size_t nextRayOff = rayOff + (size_t)n;
   const long long perTile = (long long)kBlock * items;
@@ -1531,6 +1541,12 @@ int ensurePool(RtScene* sc, size_t cap) {
   POOL_ALLOC(P.spIor, double, icap);
   POOL_ALLOC(P.counters, Counters, kCounterBlocks);
 #undef POOL_ALLOC
+  // (no kernel reads a hit it was not given, see tracedRays; a fresh pool still starts as "no hit" everywhere)
+  if (hipMemset(P.hitPrim, 0xff, sizeof(int) * cap) != hipSuccess) {
+    (void)hipGetLastError();
+    sc->freePool();
+    return fail(RT_ERR_DEVICE, "cannot clear the ray pool");
+  }
   P.cap = cap;
   sc->poolLights = nl;
   return RT_OK;
@@ -1741,6 +1757,7 @@ int renderBatch(RenderCtx& cx, long long first, int count, long long* slotsUsed,
     else { if (cx.wantStats) launchTrace<false, true>(sc, P, est, R); else launchTrace<false, false>(sc, P, est, R); }
     if (timed) timedEnd(sc, sc->stream, 0);
     cx.stats.trace_launches++;
+    const long long traced = (long long)blocksFor(est, kTraceBlock) * kTraceBlock;   // rays k_trace's grid covers
     // entries per thread: enough tiles to fill the chip, few enough atomics
     const int items = (int)std::min<long long>(kMaxItems, std::max<long long>(1, est / (kBlock * 2048)));
     const unsigned int tiles = blocksFor(est, kBlock * items);
@@ -1750,14 +1767,14 @@ int renderBatch(RenderCtx& cx, long long first, int count, long long* slotsUsed,
     // nothing to show behind a ray that hits nothing, and no coefficient that would turn a zero into a NaN
     const int blackMiss = (!(rp.use_cubemap && sc->dev.cube_w > 0) && sc->finiteCoefficients) ? 1 : 0;
     if (fused) {
-      k_hit<<<tiles, kBlock, 0, sc->stream>>>(sc->dev, items, par, R, level, rp.depth - level, blackMiss, P);
+      k_hit<<<tiles, kBlock, 0, sc->stream>>>(sc->dev, items, par, R, level, rp.depth - level, blackMiss, traced, P);
     } else {
-      k_classify<<<tiles, kBlock, 0, sc->stream>>>(items, level, R, blackMiss, P);
+      k_classify<<<tiles, kBlock, 0, sc->stream>>>(items, level, R, blackMiss, traced, P);
       if (sc->hasFaces) k_surface<<<dense, kBlock, 0, sc->stream>>>(sc->dev, R, level, P);
       if (sc->surfaceRest) k_surface_rest<<<dense, kBlock, 0, sc->stream>>>(sc->dev, R, level, P);
     }
     if (rp.use_cubemap && sc->dev.cube_w > 0)
-      k_background<<<dense, kBlock, 0, sc->stream>>>(sc->dev, R, rp.filter_width, P);
+      k_background<<<dense, kBlock, 0, sc->stream>>>(sc->dev, R, rp.filter_width, traced, P);
     if (overlap) {
       HIP_TRY(hipEventRecord(sc->evSurface, sc->stream));
       HIP_TRY(hipStreamWaitEvent(sc->side, sc->evSurface, 0));
@@ -1769,8 +1786,11 @@ int renderBatch(RenderCtx& cx, long long first, int count, long long* slotsUsed,
       if (timed2) timedEnd(sc, lightStream, 1);
       cx.stats.lights_launches++;
     }
-    if (sc->intPow) k_lights<true><<<dense, kBlock, 0, lightStream>>>(sc->dev, P);
-    else k_lights<false><<<dense, kBlock, 0, lightStream>>>(sc->dev, P);
+    // shade points whose shadow queries k_shadow's grid answers (no lights: no queries to wait for)
+    const long long queried = sc->dev.n_lights > 0 ? (long long)blocksFor(est, kTraceBlock) * kTraceBlock
+                                                   : std::numeric_limits<long long>::max();
+    if (sc->intPow) k_lights<true><<<dense, kBlock, 0, lightStream>>>(sc->dev, queried, P);
+    else k_lights<false><<<dense, kBlock, 0, lightStream>>>(sc->dev, queried, P);
     if (overlap) {
       HIP_TRY(hipEventRecord(sc->evSide, sc->side));
       sidePending = true;

@@ -390,6 +390,34 @@ def test_level_estimates_and_the_redo_of_an_outgrown_batch(built, monkeypatch):
     assert frames[0][2:] == frames[1][2:]
 
 
+def test_outgrown_grids_read_nothing_they_were_not_given(built):
+    """Equal-length pixel lists with very different contents share their level
+    history: the second list's levels outgrow the grids sized for the first.  The
+    closest-hit kernel's grid is the finest, so the kernels behind it must stop
+    where it stopped (no hit record beyond was written for this level) and the
+    batch is redone.  Both kernel chains: the fused one of a triangle-only opaque
+    scene and the general one of a scene with a transmissive sphere, each on a
+    handle whose pool has just been allocated."""
+    for text, depth in ((common.small_heightfield_scene(n=40), 4), (scenes.simple_scene(), 4)):
+        hs = host.HostScene(text=text)
+        p, _ = host.render_params(160, 160, depth=depth, traversal=abi.RT_TRAVERSE_FAST)
+        ref_rgb, ref_hits, ref_st = loader.render(hs.desc_ptr, p, threads=8)
+        hit = np.argwhere(ref_hits > 0)[:, ::-1].astype(np.int32)
+        sky = np.argwhere(ref_hits == 0)[:, ::-1].astype(np.int32)
+        n = min(len(hit), len(sky), 6000)
+        assert n > 1000
+        ds = device.DeviceScene(hs.desc_ptr)
+        a, sa = ds.render_pixels(p, np.ascontiguousarray(sky[:n]))          # first time: level by level
+        a, sa = ds.render_pixels(p, np.ascontiguousarray(sky[:n]))          # from its history
+        assert sa.batches_redone == 0 and sa.rays_total == n
+        b, sb = ds.render_pixels(p, np.ascontiguousarray(hit[:n]))          # outgrows every level below 0
+        assert sb.batches_redone == 1
+        assert np.array_equal(b, ref_rgb[hit[:n, 1], hit[:n, 0]])
+        c, sc_ = ds.render_pixels(p, np.ascontiguousarray(sky[:n]))         # and back: smaller than the history
+        assert np.array_equal(c, a) and sc_.rays_total == n
+        ds.close()
+
+
 def test_near_integer_exponents_without_the_general_power(built, monkeypatch):
     """Scenes whose shininess and spot fall-off exponents are small integers up
     to rounding (32 arrives as 31.999999999999996 through Material::shininess's
