@@ -2233,8 +2233,8 @@ int rt_scene_create(const RtSceneDesc* d, RtScene** out) {
           F.a0 = T.v0[ax]; F.a1 = T.v0[ay];
           F.b0 = T.v1[ax]; F.b1 = T.v1[ay];
           F.c0 = T.v2[ax]; F.c1 = T.v2[ay];
-          F.abc = T.abc;
-          F.axes = ax | (ay << 2);
+          F.abc2 = T.abc * 2;            // exact
+          F.axes = (ax == 1 ? 1 : 0) | (ay == 2 ? 2 : 0);
           F.face = T.face;
         }
         DevTriFast* ft; HIP_TRY(upload(fastTris.data(), fastTris.size(), &ft)); keep(ft); D.bvhTrisFast = ft;

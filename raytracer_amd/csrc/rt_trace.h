@@ -51,8 +51,8 @@ struct DevTriFast {
   double n[3];
   double dconst;
   double a0, a1, b0, b1, c0, c1;
-  double abc;
-  int axes;       // ax | (ay << 2)
+  double abc2;    // twice the projected area: the three sub-areas are summed without their halvings (exact scalings)
+  int axes;       // bit 0: the first kept axis is y (else x); bit 1: the second kept axis is z (else y)
   int face;
 };
 
@@ -431,24 +431,30 @@ __device__ __forceinline__ bool triTest(const DevTri& T, const V3& lp, const V3&
 }
 
 // triTest<true> without barycentrics on the compact record: same operations on
-// the same values.
+// the same values, except that the three halvings of the sub-areas and of the
+// triangle's area are left out on both sides of the comparison (powers of two:
+// exact) and the two kept coordinates of the hit point are picked by two
+// selects (the kept axes are (y,z), (x,z) or (x,y)).  rCull: a plane distance
+// beyond it cannot matter to the caller (it lies behind the best hit / the light).
 __device__ __forceinline__ bool triTestFast(const DevTriFast& T, const V3& lp, const V3& ld, bool cullBack,
-                                            double& rayT) {
+                                            double rCull, double& rayT) {
   const V3 n(T.n);
   const double nd = dot(n, ld);
   if (cullBack && nd > 0) return false;
   if (nd == 0) return false;
   rayT = -(dot(n, lp) + T.dconst) / nd;
   if (rayT < RT_EPS) return false;
+#ifndef RT_NO_RCULL
+  if (rayT > rCull) return false;
+#endif
   const V3 P = lp + rayT * ld;
-  const int ax = T.axes & 3, ay = (T.axes >> 2) & 3;
   const double a0 = T.a0, a1 = T.a1, b0 = T.b0, b1 = T.b1, c0 = T.c0, c1 = T.c1;
-  const double p0 = P.get(ax), p1 = P.get(ay);
-  const double pbc = fabs((b0 - p0) * (c1 - p1) - (b1 - p1) * (c0 - p0)) / 2;
-  const double apc = fabs((p0 - a0) * (c1 - a1) - (p1 - a1) * (c0 - a0)) / 2;
-  const double abp = fabs((b0 - a0) * (p1 - a1) - (b1 - a1) * (p0 - a0)) / 2;
+  const double p0 = (T.axes & 1) ? P.y : P.x, p1 = (T.axes & 2) ? P.z : P.y;
+  const double pbc = fabs((b0 - p0) * (c1 - p1) - (b1 - p1) * (c0 - p0));
+  const double apc = fabs((p0 - a0) * (c1 - a1) - (p1 - a1) * (c0 - a0));
+  const double abp = fabs((b0 - a0) * (p1 - a1) - (b1 - a1) * (p0 - a0));
   const double s = pbc + apc + abp;
-  return s <= T.abc * (1 + RT_EPS) && s >= T.abc * (1 - RT_EPS);
+  return s <= T.abc2 * (1 + RT_EPS) && s >= T.abc2 * (1 - RT_EPS);
 }
 
 // Local bounding box of a face = componentwise extrema of its vertices
@@ -657,8 +663,15 @@ __device__ int traceKdReference(const DevScene& S, const V3& p, const V3& d, int
 // array in scratch memory, which most rays never reach.  (With the whole stack
 // in scratch, two thirds of the bytes the closest-hit kernel wrote to HBM were
 // stack entries leaving the caches.)
+//
+// A node visit writes its (up to three) new entries WITHOUT branches: each
+// candidate is stored at the lane's top of stack and the top moves up only if
+// the candidate counts, so a candidate that does not count is overwritten by the
+// next store.  That needs three free rows above the top; as long as every lane
+// of the wavefront has them (checked with one comparison per visit) the visit
+// is straight-line code.
 #ifndef RT_LDS_STACK
-#define RT_LDS_STACK 8
+#define RT_LDS_STACK 11
 #endif
 typedef __attribute__((address_space(3))) uint32_t rt_lds_u32;
 typedef __attribute__((address_space(3))) unsigned long long rt_lds_u64;
@@ -667,6 +680,59 @@ typedef __attribute__((address_space(3))) unsigned long long rt_lds_u64;
 // are 8 bytes (subtree, entry distance), occlusion entries 4 (subtree).
 #define RT_LDS_STACK_BYTES_CLOSEST (RT_LDS_STACK * 8)
 #define RT_LDS_STACK_BYTES_ANYHIT (RT_LDS_STACK * 4)
+
+template <bool ANYHIT> struct BvhSlot;
+template <> struct BvhSlot<false> {   // closest hit: subtree and its entry distance
+  typedef rt_lds_u64 lds_t;
+  typedef unsigned long long word_t;
+  static __device__ __forceinline__ word_t pack(int ref, float tn) {
+    return ((unsigned long long)__float_as_uint(tn) << 32) | (uint32_t)ref;
+  }
+  static __device__ __forceinline__ int refOf(word_t w) { return (int)(uint32_t)w; }
+  static __device__ __forceinline__ float tnOf(word_t w) { return __uint_as_float((uint32_t)(w >> 32)); }
+};
+template <> struct BvhSlot<true> {    // occlusion: every overlapped subtree is searched, no distance needed
+  typedef rt_lds_u32 lds_t;
+  typedef uint32_t word_t;
+  static __device__ __forceinline__ word_t pack(int ref, float) { return (uint32_t)ref; }
+  static __device__ __forceinline__ int refOf(word_t w) { return (int)w; }
+  static __device__ __forceinline__ float tnOf(word_t) { return 0.0f; }
+};
+
+// Three-operand minimum / maximum as the instructions they are.  (Written as
+// fminf / fmaxf the compiler first passes every operand that comes out of the
+// packed multiply-adds through a quieting v_max_f32 x, x: eight extra
+// instructions per node.  No operand here can be a NaN: planes, reciprocals and
+// offsets are finite, see bvhRaySetup.)
+__device__ __forceinline__ float max3f(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ float min3f(float a, float b, float c) {
+  float r;
+  asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ float min2f(float a, float b) {
+  float r;
+  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
+// One bit per lane of the wavefront, in a scalar register pair: the outcome of
+// a per-lane test as the comparison instruction leaves it.  Combining such
+// masks is scalar work; a lane picks between two values by its bit with one
+// v_cndmask.  (Left to itself the compiler turns tests that are used in more
+// than one basic block into 0/1 integers in vector registers and combines
+// those: a dozen vector instructions per node visit.)
+typedef unsigned long long rt_mask;
+__device__ __forceinline__ unsigned int pickByMask(unsigned int ifClear, unsigned int ifSet, rt_mask m) {
+  unsigned int r;
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(ifClear), "v"(ifSet), "s"(m));
+  return r;
+}
+typedef __attribute__((address_space(3))) unsigned char rt_lds_u8;
 
 __device__ __forceinline__ float roundDownF(double x) {
   float f = (float)x;
@@ -822,9 +888,9 @@ __device__ __forceinline__ void bvhNodeSlabs(const DevScene& S, const V3& p, con
     const rt_f2 nx = slab2(q0x, c, bx, a0x), fx = slab2(q1x, c, bx, a1x);
     const rt_f2 ny = slab2(q0y, c, by, a0y), fy = slab2(q1y, c, by, a1y);
     const rt_f2 nz = slab2(q0z, c, bz, a0z), fz = slab2(q1z, c, bz, a1z);
-    const float tnear0 = fmaxf(fmaxf(nx.x, ny.x), nz.x), tnear1 = fmaxf(fmaxf(nx.y, ny.y), nz.y);
-    const float tfar0 = fminf(fminf(fminf(fx.x, fy.x), fz.x), bestTf);
-    const float tfar1 = fminf(fminf(fminf(fx.y, fy.y), fz.y), bestTf);
+    const float tnear0 = max3f(nx.x, ny.x, nz.x), tnear1 = max3f(nx.y, ny.y, nz.y);
+    const float tfar0 = min2f(min3f(fx.x, fy.x, fz.x), bestTf);
+    const float tfar1 = min2f(min3f(fx.y, fy.y, fz.y), bestTf);
     // (an unused slot has an inverted box; should rounding ever let one pass,
     // it leads to a leaf of one null triangle)
     const bool h0 = (tnear0 <= tfar0) & (tfar0 >= 0.0f);
@@ -851,7 +917,7 @@ typedef int rt_i4 __attribute__((ext_vector_type(4)));
 template <bool RAW>
 __device__ __forceinline__ void bvhNodeSlabsUniform(const DevScene& S, const BvhRay& r, int ref, unsigned int negMask,
                                                     unsigned int copy, float bestTf, float tn[4], int kid[4],
-                                                    bool hit[4]) {
+                                                    rt_mask hit[4]) {
   const float kInf = __int_as_float(0x7f800000);
   // eight copies of every node, one per combination of direction signs, each
   // with its children listed near to far for directions of those signs
@@ -895,14 +961,15 @@ __device__ __forceinline__ void bvhNodeSlabsUniform(const DevScene& S, const Bvh
     RT_PKFMA(fy, pfy, ivXY, aY, "op_sel:[0,1,1] op_sel_hi:[1,1,1]");    // planes * ivy + a1y
     RT_PKFMA(nz, pnz, ivZZ, aZ, "op_sel_hi:[1,0,0]");                   // planes * ivz + a0z
     RT_PKFMA(fz, pfz, ivZZ, aZ, "op_sel:[0,0,1] op_sel_hi:[1,0,1]");    // planes * ivz + a1z
-    const float tnear0 = fmaxf(fmaxf(nx.x, ny.x), nz.x), tnear1 = fmaxf(fmaxf(nx.y, ny.y), nz.y);
-    const float tfar0 = fminf(fminf(fminf(fx.x, fy.x), fz.x), bestTf);
-    const float tfar1 = fminf(fminf(fminf(fx.y, fy.y), fz.y), bestTf);
+    const float tnear0 = max3f(nx.x, ny.x, nz.x), tnear1 = max3f(nx.y, ny.y, nz.y);
+    const float tfar0 = min2f(min3f(fx.x, fy.x, fz.x), bestTf);
+    const float tfar1 = min2f(min3f(fx.y, fy.y, fz.y), bestTf);
     const bool h0 = (tnear0 <= tfar0) & (tfar0 >= 0.0f);
     const bool h1 = (tnear1 <= tfar1) & (tfar1 >= 0.0f);
     if (RAW) {
       tn[c] = tnear0; tn[c + 1] = tnear1;
-      hit[c] = h0; hit[c + 1] = h1;
+      hit[c] = __ballot(tnear0 <= tfar0) & __ballot(tfar0 >= 0.0f);
+      hit[c + 1] = __ballot(tnear1 <= tfar1) & __ballot(tfar1 >= 0.0f);
     } else {
       tn[c] = h0 ? tnear0 : kInf;
       tn[c + 1] = h1 ? tnear1 : kInf;
@@ -918,7 +985,7 @@ __device__ __forceinline__ void bvhNodeSlabsUniform(const DevScene& S, const Bvh
 // arrive near to far.  No axis-parallel component (the caller checked).
 template <bool RAW>
 __device__ __forceinline__ void bvhNodeSlabsLane(const DevScene& S, const BvhRay& r, int ref, unsigned int copy,
-                                                 float bestTf, float tn[4], int kid[4], bool hit[4]) {
+                                                 float bestTf, float tn[4], int kid[4], rt_mask hit[4]) {
   const float kInf = __int_as_float(0x7f800000);
   const char* base = reinterpret_cast<const char*>(S.bvhF);
   const unsigned int node = ((unsigned int)ref * 8u + copy) * 128u;   // (node count checked at scene creation)
@@ -947,14 +1014,15 @@ __device__ __forceinline__ void bvhNodeSlabsLane(const DevScene& S, const BvhRay
     RT_PKFMA_V(fy, pfy, ivXY, aY, "op_sel:[0,1,1] op_sel_hi:[1,1,1]");    // planes * ivy + a1y
     RT_PKFMA_V(nz, pnz, ivZZ, aZ, "op_sel_hi:[1,0,0]");                   // planes * ivz + a0z
     RT_PKFMA_V(fz, pfz, ivZZ, aZ, "op_sel:[0,0,1] op_sel_hi:[1,0,1]");    // planes * ivz + a1z
-    const float tnear0 = fmaxf(fmaxf(nx.x, ny.x), nz.x), tnear1 = fmaxf(fmaxf(nx.y, ny.y), nz.y);
-    const float tfar0 = fminf(fminf(fminf(fx.x, fy.x), fz.x), bestTf);
-    const float tfar1 = fminf(fminf(fminf(fx.y, fy.y), fz.y), bestTf);
+    const float tnear0 = max3f(nx.x, ny.x, nz.x), tnear1 = max3f(nx.y, ny.y, nz.y);
+    const float tfar0 = min2f(min3f(fx.x, fy.x, fz.x), bestTf);
+    const float tfar1 = min2f(min3f(fx.y, fy.y, fz.y), bestTf);
     const bool h0 = (tnear0 <= tfar0) & (tfar0 >= 0.0f);
     const bool h1 = (tnear1 <= tfar1) & (tfar1 >= 0.0f);
     if (RAW) {
       tn[c] = tnear0; tn[c + 1] = tnear1;
-      hit[c] = h0; hit[c + 1] = h1;
+      hit[c] = __ballot(tnear0 <= tfar0) & __ballot(tfar0 >= 0.0f);
+      hit[c + 1] = __ballot(tnear1 <= tfar1) & __ballot(tfar1 >= 0.0f);
     } else {
       tn[c] = h0 ? tnear0 : kInf;
       tn[c + 1] = h1 ? tnear1 : kInf;
@@ -993,6 +1061,9 @@ __device__ __forceinline__ bool sceneOrderBefore(const DevScene& S, int prim, in
 // The primitives of leaf reference `ref` (< 0).  Closest hit: updates the best
 // hit.  Occlusion: returns true at the first hit that satisfies the reference's
 // test |(p + t d) - p|^2 < occDist2 (occDist2 < 0: any hit), with tHit set.
+// rCull: object-space plane distances beyond it are of no interest (closest
+// hit: they lie behind the best hit so far, and rCull follows it; occlusion:
+// behind the light).
 //
 // TRI: the scene holds nothing but triangles of identity-transform meshes (the
 // caller checked), so the code for the other primitive kinds and for object
@@ -1000,8 +1071,8 @@ __device__ __forceinline__ bool sceneOrderBefore(const DevScene& S, int prim, in
 // registers even when it never runs.
 template <bool ANYHIT, bool STATS, bool TRI>
 __device__ __forceinline__ bool bvhLeaf(const DevScene& S, const V3& p, const V3& d, const BvhRay& r, int ref,
-                                        double occDist2, bool& haveOne, double& bestT, float& bestTf, int& bestPrim,
-                                        double& tHit, TraceCounters& cnt) {
+                                        double occDist2, bool& haveOne, double& bestT, float& bestTf, double& rCull,
+                                        int& bestPrim, double& tHit, TraceCounters& cnt) {
   const int x = ~ref;
   if (!TRI && (x & RT_BVH_OBJECT_BIT)) {
     const int oi = x & 0x3fffffff;
@@ -1030,7 +1101,7 @@ __device__ __forceinline__ bool bvhLeaf(const DevScene& S, const V3& p, const V3
       int face;
       if (TRI) {
         const DevTriFast& T = S.bvhTrisFast[first + k];
-        hit = triTestFast(T, p, r.ldI, r.cullBack, rt);
+        hit = triTestFast(T, p, r.ldI, r.cullBack, rCull, rt);
         tw = rt / r.lenI;
         face = T.face;
       } else {
@@ -1055,6 +1126,8 @@ __device__ __forceinline__ bool bvhLeaf(const DevScene& S, const V3& p, const V3
       } else if (!haveOne || tw < bestT || (tw == bestT && sceneOrderBefore(S, RT_PRIM_FACE | face, bestPrim))) {
         haveOne = true; bestT = tw; bestPrim = RT_PRIM_FACE | face;
         bestTf = roundUpF(bestT);
+        // rt / lenI <= bestT implies rt <= bestT * lenI * (1 + 2^-52); a hair more
+        if (TRI) rCull = (bestT * r.lenI) * (1.0 + 1.0e-12);
       }
     }
   }
@@ -1109,60 +1182,94 @@ __device__ int traceBvh(const DevScene& S, const V3& p, const V3& d, int rayType
   bool haveOne = false;
   double bestT = tLimit;   // doubles as the far cull bound until a hit exists
   float bestTf = roundUpF(bestT);
+  // plane distances (object space of the identity-transform meshes) that cannot matter, see bvhLeaf
+  double rCull = (tLimit * r.lenI) * (1.0 + 1.0e-12);
   int bestPrim = RT_PRIM_NONE;
-  const unsigned int ldsStride = blockDim.x;
-  rt_lds_u32* const col32 = ldsStack + threadIdx.x;
-  rt_lds_u64* const col64 = (rt_lds_u64*)ldsStack + threadIdx.x;
-  unsigned long long deep[RT_BVH_STACK - RT_LDS_STACK];   // entries past the LDS part
-  int sp = 0;
-#define RT_STACK_STORE(K, R, T)                                                    \
-  {                                                                                \
-    if ((K) < RT_LDS_STACK) {                                                      \
-      if (ANYHIT) col32[(unsigned int)(K) * ldsStride] = (uint32_t)(R);            \
-      else col64[(unsigned int)(K) * ldsStride] =                                  \
-          ((unsigned long long)__float_as_uint(T) << 32) | (uint32_t)(R);          \
-    } else {                                                                       \
-      deep[(K) - RT_LDS_STACK] =                                                   \
-          ((unsigned long long)__float_as_uint(T) << 32) | (uint32_t)(R);          \
-    }                                                                              \
-  }
-#define RT_STACK_LOAD(K, R, T)                                                     \
-  {                                                                                \
-    if ((K) < RT_LDS_STACK) {                                                      \
-      if (ANYHIT) {                                                                \
-        R = (int)col32[(unsigned int)(K) * ldsStride];                             \
-      } else {                                                                     \
-        const unsigned long long e_ = col64[(unsigned int)(K) * ldsStride];        \
-        R = (int)(uint32_t)e_;                                                     \
-        T = __uint_as_float((uint32_t)(e_ >> 32));                                 \
-      }                                                                            \
-    } else {                                                                       \
-      const unsigned long long e_ = deep[(K) - RT_LDS_STACK];                      \
-      R = (int)(uint32_t)e_;                                                       \
-      T = __uint_as_float((uint32_t)(e_ >> 32));                                   \
-    }                                                                              \
-  }
-#ifdef RT_STACK_NOTOP
-  // every entry in memory (depth checked at scene creation)
-#define RT_BVH_PUSH(R, T) { RT_STACK_STORE(sp, R, T) sp++; }
-#else
-  // The newest stack entry stays in registers (topRef / topTn), the rest in
-  // LDS (see RT_LDS_STACK): a pop then hands out the register entry at once and
-  // the load that refills it overlaps the work on the popped subtree.
+
+  typedef BvhSlot<ANYHIT> Slot;
+  typedef typename Slot::lds_t lds_t;
+  typedef typename Slot::word_t word_t;
+  const unsigned int stride = blockDim.x;
+  lds_t* const base = (lds_t*)ldsStack + threadIdx.x;
+  lds_t* const ldsEnd = base + RT_LDS_STACK * stride;
+  lds_t* const fastLimit = base + (RT_LDS_STACK - 3) * stride;   // a visit may write three rows at the top
+  lds_t* top = base;                                             // next free row of this lane
+  word_t deep[RT_BVH_STACK - RT_LDS_STACK];                      // entries past the LDS part (depth checked at scene creation)
+  int nDeep = 0;
+  const float kInf = __int_as_float(0x7f800000);
+
+  // One visit's new entries.  Children 0..3 are ordered near to far, the masks
+  // say which of them each lane's ray enters: the nearest of those is visited
+  // next, the others go onto the stack farthest first.
+  const unsigned int rowBytes = stride * (unsigned int)sizeof(word_t);
+#ifdef RT_STACK_TOP
+  // The newest entry stays in registers (topRef / topTn); a new entry moves it
+  // to the LDS rows.  A pop then hands the register entry out at once and the
+  // load that refills it overlaps the work on the popped subtree.
   int topRef = RT_BVH_EMPTY;
   float topTn = 0.0f;
-#define RT_BVH_PUSH(R, T)                                                          \
-  {                                                                                \
-    if (topRef != RT_BVH_EMPTY) {   /* depth checked at scene creation */          \
-      RT_STACK_STORE(sp, topRef, topTn)                                            \
-      sp++;                                                                        \
-    }                                                                              \
-    topRef = (R);                                                                  \
-    topTn = (T);                                                                   \
+#define RT_DESCEND_STEP(C, P)                                                                      \
+      *(lds_t*)t_ = Slot::pack(topRef, topTn); t_ += pickByMask(0u, rowBytes, (P) & valid_);       \
+      topRef = (int)pickByMask((unsigned int)topRef, (unsigned int)kid[C], (P));                   \
+      topTn = __uint_as_float(pickByMask(__float_as_uint(topTn), __float_as_uint(tn[C]), (P)));    \
+      valid_ |= (P);
+#define RT_DESCEND(M0, M1, M2, M3)                                                                 \
+  {                                                                                                \
+    const rt_mask m0_ = (M0), m1_ = (M1), m2_ = (M2), m3_ = (M3);                                  \
+    const rt_mask p3_ = m3_ & (m0_ | m1_ | m2_), p2_ = m2_ & (m0_ | m1_), p1_ = m1_ & m0_;         \
+    if (__ballot(top > fastLimit) == 0) {                                                          \
+      rt_lds_u8* t_ = (rt_lds_u8*)top;                                                             \
+      rt_mask valid_ = __ballot(topRef != RT_BVH_EMPTY);                                           \
+      RT_DESCEND_STEP(3, p3_) RT_DESCEND_STEP(2, p2_) RT_DESCEND_STEP(1, p1_)                      \
+      top = (lds_t*)t_;                                                                            \
+    } else {                                                                                       \
+      if (pickByMask(0u, 1u, p3_)) RT_PUSH_TOP_SLOW(kid[3], tn[3])                                 \
+      if (pickByMask(0u, 1u, p2_)) RT_PUSH_TOP_SLOW(kid[2], tn[2])                                 \
+      if (pickByMask(0u, 1u, p1_)) RT_PUSH_TOP_SLOW(kid[1], tn[1])                                 \
+    }                                                                                              \
+    unsigned int next_ = pickByMask((unsigned int)RT_BVH_EMPTY, (unsigned int)kid[3], m3_);        \
+    next_ = pickByMask(next_, (unsigned int)kid[2], m2_);                                          \
+    next_ = pickByMask(next_, (unsigned int)kid[1], m1_);                                          \
+    ref = (int)pickByMask(next_, (unsigned int)kid[0], m0_);                                       \
+  }
+#define RT_PUSH_TOP_SLOW(R, T)                                                                     \
+  {                                                                                                \
+    if (topRef != RT_BVH_EMPTY) RT_PUSH_SLOW(topRef, topTn)                                        \
+    topRef = (R); topTn = (T);                                                                     \
+  }
+#else
+#ifndef RT_PUSH_ALWAYS
+#define RT_PUSH_ALWAYS 0
+#endif
+  // (a slot that no lane of the wavefront uses is skipped as a whole -- rays of a
+  // wavefront mostly enter the same children; inside a slot no lane branches)
+#define RT_DESCEND(M0, M1, M2, M3)                                                                 \
+  {                                                                                                \
+    const rt_mask m0_ = (M0), m1_ = (M1), m2_ = (M2), m3_ = (M3);                                  \
+    const rt_mask p3_ = m3_ & (m0_ | m1_ | m2_), p2_ = m2_ & (m0_ | m1_), p1_ = m1_ & m0_;         \
+    if (__ballot(top > fastLimit) == 0) {                                                          \
+      rt_lds_u8* t_ = (rt_lds_u8*)top;                                                             \
+      if (RT_PUSH_ALWAYS || p3_) { *(lds_t*)t_ = Slot::pack(kid[3], tn[3]); t_ += pickByMask(0u, rowBytes, p3_); }   \
+      if (RT_PUSH_ALWAYS || p2_) { *(lds_t*)t_ = Slot::pack(kid[2], tn[2]); t_ += pickByMask(0u, rowBytes, p2_); }   \
+      if (RT_PUSH_ALWAYS || p1_) { *(lds_t*)t_ = Slot::pack(kid[1], tn[1]); t_ += pickByMask(0u, rowBytes, p1_); }   \
+      top = (lds_t*)t_;                                                                            \
+    } else {                                                                                       \
+      if (pickByMask(0u, 1u, p3_)) RT_PUSH_SLOW(kid[3], tn[3])                                     \
+      if (pickByMask(0u, 1u, p2_)) RT_PUSH_SLOW(kid[2], tn[2])                                     \
+      if (pickByMask(0u, 1u, p1_)) RT_PUSH_SLOW(kid[1], tn[1])                                     \
+    }                                                                                              \
+    unsigned int next_ = pickByMask((unsigned int)RT_BVH_EMPTY, (unsigned int)kid[3], m3_);        \
+    next_ = pickByMask(next_, (unsigned int)kid[2], m2_);                                          \
+    next_ = pickByMask(next_, (unsigned int)kid[1], m1_);                                          \
+    ref = (int)pickByMask(next_, (unsigned int)kid[0], m0_);                                       \
   }
 #endif
-  int ref = 0;
-  const float kInf = __int_as_float(0x7f800000);
+#define RT_PUSH_SLOW(R, T)                                                                         \
+  {                                                                                                \
+    if (top != ldsEnd) { *top = Slot::pack(R, T); top += stride; }                                 \
+    else deep[nDeep++] = Slot::pack(R, T);                                                         \
+  }
+
 #ifndef RT_NO_UNIFORM_PATH
   // wavefront-wide facts about the rays that are still here: do they share their
   // direction signs, and is none of them parallel to an axis
@@ -1172,6 +1279,7 @@ __device__ int traceBvh(const DevScene& S, const V3& p, const V3& d, int rayType
   // this lane can read the binary32 planes by itself: no axis-parallel component, offsets fit 32 bits
   const bool laneOk = S.bvhLaneF && !(r.zx | r.zy | r.zz);
 #endif
+  int ref = 0;
   for (;;) {
     if (ref >= 0) {
 #ifdef RT_DIVERGENCE_STATS   // diagnostics build: count wavefront iterations instead of lane visits
@@ -1190,106 +1298,93 @@ __device__ int traceBvh(const DevScene& S, const V3& p, const V3& d, int rayType
 #ifndef RT_NO_UNIFORM_PATH
       // Three node visits in four find every lane of the wavefront at the same
       // node (neighbouring samples, neighbouring shade points): those take the
-      // scalar form of the slab test.  A closest-hit query reads the copy of
-      // the node that lists its children near to far for the wavefront's
-      // direction signs (by box centre along the signs' diagonal, fixed when the
-      // scene was created), takes the first child hit next and pushes the others
-      // farthest first, without a per-lane sort.  The order is only nearly the order of entry distances; a closer
-      // hit found late still culls what was pushed before it (pop), so the
-      // result does not depend on it.  (Mesh scenes only: in the kernels that
-      // also carry the code of the other primitive kinds the extra registers
-      // push them over an occupancy step.)
+      // scalar form of the slab test, on the copy of the node that lists its
+      // children near to far for the wavefront's direction signs (by box centre
+      // along the signs' diagonal, fixed when the scene was created): no
+      // per-lane sort.  The order is only nearly the order of entry distances;
+      // a closer hit found late still culls what was pushed before it (pop), so
+      // the result does not depend on it.  (Mesh scenes only: in the kernels
+      // that also carry the code of the other primitive kinds the extra
+      // registers push them over an occupancy step.)
       const int uref = __builtin_amdgcn_readfirstlane(ref);
       const bool sameNode = TRI && uniformOk && __ballot(ref != uref) == 0;
-      if (TRI && !ANYHIT && sameNode) {
-        bool hk[4];
+      if (TRI && sameNode) {
+        rt_mask hk[4];
         bvhNodeSlabsUniform<true>(S, r, uref, negMask, negMask, bestTf, tn, kid, hk);
-        const bool h0 = hk[0], h1 = hk[1], h2 = hk[2], h3 = hk[3];
-        if (h3 & (h0 | h1 | h2)) RT_BVH_PUSH(kid[3], tn[3])
-        if (h2 & (h0 | h1)) RT_BVH_PUSH(kid[2], tn[2])
-        if (h1 & h0) RT_BVH_PUSH(kid[1], tn[1])
-        if (h0 | h1 | h2 | h3) {
-          ref = h0 ? kid[0] : h1 ? kid[1] : h2 ? kid[2] : kid[3];
-          continue;
-        }
+        RT_DESCEND(hk[0], hk[1], hk[2], hk[3])
+      } else if (TRI && ANYHIT && laneOk) {
+        // an occlusion query's lane at a node of its own: the same binary32
+        // planes through vector loads, the copy for its own direction signs
+        // (for closest-hit queries the quantised node and a sort were measured
+        // faster: 64 instead of 112 bytes per visit)
+        rt_mask hk[4];
+        bvhNodeSlabsLane<true>(S, r, ref, myNeg, bestTf, tn, kid, hk);
+        RT_DESCEND(hk[0], hk[1], hk[2], hk[3])
       } else
 #endif
       {
-#ifndef RT_NO_UNIFORM_PATH
-      // (occlusion queries visit every overlapped subtree whatever the order:
-      // they all read copy 0 and pick the nearest child as below; measured:
-      // taking the first overlapped child instead costs 8 %.  Their lanes that
-      // are at a node of their own read the same binary32 planes through vector
-      // loads; for closest-hit queries that was measured slower than the
-      // quantised node and its sort, 15.1 against 14.6 ms.)
-      if (TRI && ANYHIT && sameNode) bvhNodeSlabsUniform<false>(S, r, uref, negMask, 0u, bestTf, tn, kid, nullptr);
-      else if (TRI && ANYHIT && laneOk) bvhNodeSlabsLane<false>(S, r, ref, 0u, bestTf, tn, kid, nullptr);
-      else
-#endif
-      bvhNodeSlabs(S, p, r, ref, bestTf, tn, kid);
-      if (ANYHIT) {
-        // Every overlapped subtree has to be searched unless an occluder turns
-        // up, so only the descent wants an order: nearest child next, the
-        // others onto the stack as they come (no distance needed at the pop).
-        float tb = tn[0];
-        int kb = kid[0];
-#pragma unroll
-        for (int c = 1; c < 4; c++) {
-          const bool nearer = tn[c] < tb;
-          const float to = nearer ? tb : tn[c];
-          const int ko = nearer ? kb : kid[c];
-          tb = nearer ? tn[c] : tb;
-          kb = nearer ? kid[c] : kb;
-          if (to < kInf) RT_BVH_PUSH(ko, 0.0f)
-        }
-        if (tb < kInf) { ref = kb; continue; }
-      } else {
+        bvhNodeSlabs(S, p, r, ref, bestTf, tn, kid);
         bvhSort4(tn, kid);
-        if (tn[0] < kInf) {
-          // farthest first onto the stack, the nearest child is visited next
-          if (tn[3] < kInf) RT_BVH_PUSH(kid[3], tn[3])
-          if (tn[2] < kInf) RT_BVH_PUSH(kid[2], tn[2])
-          if (tn[1] < kInf) RT_BVH_PUSH(kid[1], tn[1])
-          ref = kid[0];
-          continue;
-        }
+        RT_DESCEND(__ballot(tn[0] < kInf), __ballot(tn[1] < kInf), __ballot(tn[2] < kInf), __ballot(tn[3] < kInf))
       }
-      }
+      // (The shape of this loop matters: with this `continue` the compiler keeps
+      // the lanes that are still descending in a loop of node visits of their
+      // own and parks the lanes that have reached a leaf or need a pop until
+      // the last of them has, so that the triangle tests below run with as many
+      // lanes as the wavefront can muster.  Without it every iteration runs a
+      // node visit, a leaf and a pop for whichever lanes want one: a third more
+      // vector-memory instructions and 13 % more time.)
+      if (ref != RT_BVH_EMPTY) continue;
     } else {
       double tHit;
-      if (bvhLeaf<ANYHIT, STATS, TRI>(S, p, d, r, ref, occDist2, haveOne, bestT, bestTf, bestPrim, tHit, cnt)) {
+      if (bvhLeaf<ANYHIT, STATS, TRI>(S, p, d, r, ref, occDist2, haveOne, bestT, bestTf, rCull, bestPrim, tHit, cnt)) {
         tOut = tHit;
         return 0;
       }
     }
-    // pop the next subtree that can still contain a closer hit
-    bool found = false;
-#ifdef RT_STACK_NOTOP
-    while (sp > 0) {
-      --sp;
-      int candRef;
-      float candTn = 0.0f;
-      RT_STACK_LOAD(sp, candRef, candTn)
-      if (ANYHIT || (double)candTn <= bestT) { ref = candRef; found = true; break; }
-    }
-#else
-    while (topRef != RT_BVH_EMPTY) {
-      const int candRef = topRef;
-      const float candTn = topTn;
-      if (sp > 0) {
-        --sp;
-        RT_STACK_LOAD(sp, topRef, topTn)
-      } else {
-        topRef = RT_BVH_EMPTY;
+    {
+      ref = RT_BVH_EMPTY;
+      // pop the next subtree that can still contain a closer hit
+#ifdef RT_STACK_TOP
+      while (topRef != RT_BVH_EMPTY) {
+        const int candRef = topRef;
+        const float candTn = topTn;
+        if (nDeep > 0) {
+          const word_t e = deep[--nDeep];
+          topRef = Slot::refOf(e); topTn = Slot::tnOf(e);
+        } else if (top != base) {
+          top -= stride;
+          const word_t e = *top;
+          topRef = Slot::refOf(e); topTn = Slot::tnOf(e);
+        } else {
+          topRef = RT_BVH_EMPTY;
+        }
+        if (ANYHIT || candTn <= bestTf) { ref = candRef; break; }
       }
-      if (ANYHIT || (double)candTn <= bestT) { ref = candRef; found = true; break; }
-    }
+#else
+      if (__ballot(nDeep > 0) == 0) {
+        while (top != base) {
+          top -= stride;
+          const word_t e = *top;
+          if (ANYHIT || Slot::tnOf(e) <= bestTf) { ref = Slot::refOf(e); break; }
+        }
+      } else {
+        for (;;) {
+          word_t e;
+          if (nDeep > 0) e = deep[--nDeep];
+          else if (top != base) { top -= stride; e = *top; }
+          else break;
+          if (ANYHIT || Slot::tnOf(e) <= bestTf) { ref = Slot::refOf(e); break; }
+        }
+      }
 #endif
-    if (!found) break;
+      if (ref == RT_BVH_EMPTY) break;
+    }
   }
-#undef RT_STACK_STORE
-#undef RT_STACK_LOAD
-#undef RT_BVH_PUSH
+#undef RT_DESCEND
+#undef RT_PUSH_SLOW
+#undef RT_DESCEND_STEP
+#undef RT_PUSH_TOP_SLOW
   tOut = haveOne ? bestT : 0.0;
   return bestPrim;
 }
