@@ -134,6 +134,8 @@ def main():
     if world != args.gpus and rank == 0:
         log("[bench] note: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world))
 
+    # the roofline needs the duration of every traversal launch of the timed steps
+    os.environ.setdefault("RT_AMD_LAUNCH_EVENTS", "1")
     hs, width, height, kw, desc = build_scene(args.config, args.scale)
     trav = abi.RT_TRAVERSE_FAST if args.traversal == "fast" else abi.RT_TRAVERSE_REFERENCE
     t_create = time.perf_counter()

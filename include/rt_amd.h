@@ -190,10 +190,11 @@ typedef struct RtStats {
   unsigned long long shade_points;
   double ms_total;           /* host wall time of the call */
   double ms_device;          /* HIP-event time of all kernels of the call */
-  double ms_trace;           /* HIP-event time of the closest-hit launches (k_trace) */
+  double ms_trace;           /* HIP-event time of the closest-hit launches (k_trace); 0 unless collect_stats is set
+                                or the scene was created under RT_AMD_LAUNCH_EVENTS=1 (the events cost a little) */
   int    trace_launches;     /* number of those launches */
   int    batches;
-  double ms_lights;          /* HIP-event time of the shadow-query launches (k_shadow) */
+  double ms_lights;          /* HIP-event time of the shadow-query launches (k_shadow); as ms_trace */
   int    lights_launches;
   int    _pad;
   unsigned long long shadow_nodes_visited, shadow_prims_tested;  /* shadow rays' share of the two totals */

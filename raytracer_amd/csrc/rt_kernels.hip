@@ -37,6 +37,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -169,6 +170,11 @@ struct FrameMap {           // pixel slot -> pixel, for tile-ordered rendering
   int ns;                   // samples per pixel
   int aaN;                  // n (ns = n*n) or 0
   const double* jitter;     // device copy, 2*ns values or NULL
+  // x = i / width for every column i, y = j / height for every row j
+  // (RayTracer.cpp:51-52), divided once per frame size on the host -- IEEE
+  // division, the same bits -- instead of twice per primary ray
+  const double* colX;
+  const double* rowY;
   FastDiv dPer, dTilesX, dBlocksPerRow, dNs, dAaN;   // by tileW*tileH, tilesX, tileW/8, ns, aaN (setDivisors)
   // sub-sample pitch of tracePixelAntiAlias (RayTracer.cpp:84-85), the same for
   // every sample: divided once on the host (IEEE division, the same bits)
@@ -262,8 +268,8 @@ __device__ __forceinline__ RayPD primaryRay(const DevScene& S, const FrameMap& f
   const int k = (int)((unsigned int)i - rel * fm.dNs.d);
   int px, py, tk, lx, ly;
   if (!slotToPixel(fm, first, rel, px, py, tk, lx, ly)) return r;
-  double x = double(px) / double(fm.width);
-  double y = double(py) / double(fm.height);
+  double x = fm.colX[px];
+  double y = fm.rowY[py];
   if (fm.aaN > 0) {
     const int n = fm.aaN;
     const double deltaX = fm.deltaX, deltaY = fm.deltaY;
@@ -394,10 +400,12 @@ k_trace(DevScene S, RaySrc R, double* hitT, int* hitPrim, Counters* counters) {
 
 // Sets up level 0 of a batch / hands the counts of level l on to level l+1.
 // One thread: the next level's kernels are ordered behind it on the stream.
-__global__ void k_begin(Counters* c, unsigned int n) {
-  c->n = n;
-  c->rayOff = 0;
-  c->spOff = 0;
+// (k_begin also clears the counter blocks of the batch's levels: one launch
+// instead of a fill and a launch)
+__global__ void k_begin(Counters* c, unsigned int n, int blocks) {
+  unsigned int* w = reinterpret_cast<unsigned int*>(c);
+  const int words = blocks * (int)(sizeof(Counters) / sizeof(unsigned int));
+  for (int k = threadIdx.x; k < words; k += blockDim.x) w[k] = (k == (int)(offsetof(Counters, n) / sizeof(unsigned int))) ? n : 0u;
 }
 __global__ void k_advance(Counters* c, unsigned int cap) {
   Counters* next = c + 1;
@@ -1402,6 +1410,9 @@ struct RtScene {
   int growthDepth = -1;
   unsigned char* frameRgb = nullptr; int* frameHit = nullptr; size_t framePixels = 0;
   double* jitterDev = nullptr; size_t jitterCap = 0;
+  std::vector<double> jitterHost;  // what jitterDev holds
+  double* pixelXY = nullptr; int pixelXYw = 0, pixelXYh = 0;   // i / width per column, then j / height per row
+  std::vector<double> pixelXYHost;
   unsigned char* isectBuf = nullptr; size_t isectCap = 0;   // rt_intersect_batch's staging, in rays
   std::vector<hipEvent_t> events;  // pairs around traversal kernels
   size_t eventsUsed = 0;
@@ -1419,6 +1430,7 @@ struct RtScene {
   int levelSyncMode = 0;              // RT_AMD_LEVEL_SYNC=1: read every level's count back before the next
   bool finiteCoefficients = true;     // kr and kt of every material are finite (k_classify / k_hit: dropChild)
   bool intPow = true;                 // every pow exponent of the scene is near a small integer: k_lights<true>
+  bool launchEvents = false;          // RT_AMD_LAUNCH_EVENTS=1: time every traversal launch (RtStats::ms_trace, ms_lights)
   bool fusedHit = true;               // RT_AMD_FUSED_HIT=0: k_classify / k_surface / k_shade even where k_hit would do
 
   ~RtScene() {
@@ -1429,6 +1441,7 @@ struct RtScene {
     if (frameRgb) hipFree(frameRgb);
     if (frameHit) hipFree(frameHit);
     if (jitterDev) hipFree(jitterDev);
+    if (pixelXY) hipFree(pixelXY);
     if (isectBuf) hipFree(isectBuf);
     for (hipEvent_t e : events) hipEventDestroy(e);
     if (countersHost) hipHostFree(countersHost);
@@ -1640,13 +1653,18 @@ inline unsigned int blocksFor(long long est, int threads) {
 }
 
 template <bool FAST, bool STATS>
-void launchTrace(RtScene* sc, const Pool& P, long long est, const RaySrc& R) {
+long long launchTrace(RtScene* sc, const Pool& P, long long est, const RaySrc& R) {
+  // (Measured and dropped: giving the wavefronts of a thin level 16 or 32 rays
+  // instead of 64, so that more wavefronts share its rays: 10-70 % slower.  A
+  // thin level lasts as long as its longest ray, not as long as a wavefront's
+  // lanes take one after the other.)
   const unsigned int blocks = blocksFor(est, kTraceBlock);
   const size_t lds = (size_t)(FAST ? RT_LDS_STACK_BYTES_CLOSEST : RT_KD_LDS_STACK_BYTES) * kTraceBlock;
   if (FAST && sc->triOnly)
     k_trace<FAST, STATS, true><<<blocks, kTraceBlock, lds, sc->stream>>>(sc->dev, R, P.hitT, P.hitPrim, P.counters);
   else
     k_trace<FAST, STATS, false><<<blocks, kTraceBlock, lds, sc->stream>>>(sc->dev, R, P.hitT, P.hitPrim, P.counters);
+  return (long long)blocks * kTraceBlock;   // rays the grid covers
 }
 template <bool FAST, bool STATS>
 void launchShadow(RtScene* sc, hipStream_t st, const Pool& P, long long est) {
@@ -1661,7 +1679,12 @@ void launchShadow(RtScene* sc, hipStream_t st, const Pool& P, long long est) {
     k_shadow<FAST, STATS, false><<<grid, kTraceBlock, lds, st>>>(sc->dev, P);
 }
 
-bool timedBegin(RtScene* sc, hipStream_t st) {
+// HIP events around the traversal kernels (RtStats::ms_trace / ms_lights): only
+// where somebody asked for them (RT_AMD_LAUNCH_EVENTS=1 when the scene is
+// created, or a statistics pass) -- an event record between two kernels of a
+// stream costs the back-to-back dispatch of the second.
+bool timedBegin(RtScene* sc, hipStream_t st, bool wanted) {
+  if (!wanted) return false;
   if (sc->eventsUsed + 2 > sc->events.size()) {
     for (int k = 0; k < 64; k++) {
       hipEvent_t e;
@@ -1709,8 +1732,7 @@ int renderBatch(RenderCtx& cx, long long first, int count, long long* slotsUsed,
   }
   const bool haveHist = (int)hist.size() == nLevels;
   const bool levelSync = !haveHist || forceSync || sc->levelSyncMode == 1;
-  HIP_TRY(hipMemsetAsync(pool.counters, 0, sizeof(Counters) * (size_t)(nLevels + 1), sc->stream));
-  k_begin<<<1, 1, 0, sc->stream>>>(pool.counters, (unsigned int)nSamples);
+  k_begin<<<1, kBlock, 0, sc->stream>>>(pool.counters, (unsigned int)nSamples, nLevels + 1);
   // A level's shadow queries and shading depend on its shade points only, the
   // next level's rays on neither: they go to the side stream and run beside the
   // main stream's k_shade of this level and k_trace / k_classify / k_surface of
@@ -1752,12 +1774,12 @@ int renderBatch(RenderCtx& cx, long long first, int count, long long* slotsUsed,
     R.primary = level == 0 ? 1 : 0;
     R.fm = cx.fm;
     R.first = makeSlotBase(cx.fm, first);
-    const bool timed = timedBegin(sc, sc->stream);
-    if (cx.fast) { if (cx.wantStats) launchTrace<true, true>(sc, P, est, R); else launchTrace<true, false>(sc, P, est, R); }
-    else { if (cx.wantStats) launchTrace<false, true>(sc, P, est, R); else launchTrace<false, false>(sc, P, est, R); }
+    const bool timed = timedBegin(sc, sc->stream, sc->launchEvents || cx.wantStats);
+    long long traced;   // rays k_trace's grid covers
+    if (cx.fast) traced = cx.wantStats ? launchTrace<true, true>(sc, P, est, R) : launchTrace<true, false>(sc, P, est, R);
+    else traced = cx.wantStats ? launchTrace<false, true>(sc, P, est, R) : launchTrace<false, false>(sc, P, est, R);
     if (timed) timedEnd(sc, sc->stream, 0);
     cx.stats.trace_launches++;
-    const long long traced = (long long)blocksFor(est, kTraceBlock) * kTraceBlock;   // rays k_trace's grid covers
     // entries per thread: enough tiles to fill the chip, few enough atomics
     const int items = (int)std::min<long long>(kMaxItems, std::max<long long>(1, est / (kBlock * 2048)));
     const unsigned int tiles = blocksFor(est, kBlock * items);
@@ -1780,7 +1802,7 @@ int renderBatch(RenderCtx& cx, long long first, int count, long long* slotsUsed,
       HIP_TRY(hipStreamWaitEvent(sc->side, sc->evSurface, 0));
     }
     if (sc->dev.n_lights > 0) {
-      const bool timed2 = timedBegin(sc, lightStream);
+      const bool timed2 = timedBegin(sc, lightStream, sc->launchEvents || cx.wantStats);
       if (cx.fast) { if (cx.wantStats) launchShadow<true, true>(sc, lightStream, P, est); else launchShadow<true, false>(sc, lightStream, P, est); }
       else { if (cx.wantStats) launchShadow<false, true>(sc, lightStream, P, est); else launchShadow<false, false>(sc, lightStream, P, est); }
       if (timed2) timedEnd(sc, lightStream, 1);
@@ -1940,8 +1962,12 @@ int sizePool(RtScene* sc, const RtRenderParams* rp, long long slots) {
   const bool interp = sc->dev.interp_materials != 0;
   const bool opaque = sc->dev.opaque != 0;
   const size_t perSlot = poolBytesPerSlot(sc->nLights, interp, opaque);
-  size_t cap = workspaceBudgetBytes(sc->pool.cap * poolBytesPerSlot((int)sc->poolLights, interp, opaque)) / perSlot;
   const size_t want = (size_t)std::max<double>((double)slots * sc->growth * 1.1, 1 << 16);
+  // the pool in hand already holds what the frame wants and is not grossly larger: no question to the driver
+  if (rp->max_batch_samples <= 0 && sc->pool.cap >= std::min<size_t>(want, 0x3fffffff) && sc->pool.cap <= 4 * want &&
+      sc->poolLights >= (size_t)std::max(1, sc->nLights))
+    return RT_OK;
+  size_t cap = workspaceBudgetBytes(sc->pool.cap * poolBytesPerSlot((int)sc->poolLights, interp, opaque)) / perSlot;
   cap = std::min(cap, want);
   cap = std::min<size_t>(cap, 0x3fffffff);
   if (rp->max_batch_samples > 0) cap = std::min<size_t>(cap, (size_t)rp->max_batch_samples * 8);
@@ -1958,10 +1984,35 @@ int uploadJitter(RtScene* sc, const RtRenderParams* rp, int ns) {
     if (sc->jitterDev) hipFree(sc->jitterDev);
     sc->jitterDev = nullptr;
     sc->jitterCap = 0;
+    sc->jitterHost.clear();
     HIP_TRY(hipMalloc((void**)&sc->jitterDev, need * sizeof(double)));
     sc->jitterCap = need;
   }
-  HIP_TRY(hipMemcpyAsync(sc->jitterDev, rp->jitter, need * sizeof(double), hipMemcpyHostToDevice, sc->stream));
+  // (a caller renders frame after frame with one table: copy it when it differs from the one last copied)
+  if (sc->jitterHost.size() == need && std::memcmp(sc->jitterHost.data(), rp->jitter, need * sizeof(double)) == 0) return RT_OK;
+  HIP_TRY(hipStreamSynchronize(sc->stream));   // the staging vector below may still be read by an earlier copy
+  sc->jitterHost.assign(rp->jitter, rp->jitter + need);
+  HIP_TRY(hipMemcpyAsync(sc->jitterDev, sc->jitterHost.data(), need * sizeof(double), hipMemcpyHostToDevice, sc->stream));
+  return RT_OK;
+}
+
+// Pixel -> image-plane coordinate tables of a frame size (FrameMap::colX / rowY).
+int uploadPixelCoordinates(RtScene* sc, int w, int h, FrameMap& fm) {
+  if (sc->pixelXYw != w || sc->pixelXYh != h) {
+    HIP_TRY(hipStreamSynchronize(sc->stream));   // nothing in flight reads the old tables
+    if (sc->pixelXY) hipFree(sc->pixelXY);
+    sc->pixelXY = nullptr;
+    sc->pixelXYw = sc->pixelXYh = 0;
+    sc->pixelXYHost.resize((size_t)w + h);
+    for (int i = 0; i < w; i++) sc->pixelXYHost[(size_t)i] = double(i) / double(w);
+    for (int j = 0; j < h; j++) sc->pixelXYHost[(size_t)w + j] = double(j) / double(h);
+    HIP_TRY(hipMalloc((void**)&sc->pixelXY, sc->pixelXYHost.size() * sizeof(double)));
+    HIP_TRY(hipMemcpy(sc->pixelXY, sc->pixelXYHost.data(), sc->pixelXYHost.size() * sizeof(double), hipMemcpyHostToDevice));
+    sc->pixelXYw = w;
+    sc->pixelXYh = h;
+  }
+  fm.colX = sc->pixelXY;
+  fm.rowY = sc->pixelXY + w;
   return RT_OK;
 }
 
@@ -2054,6 +2105,7 @@ int rt_scene_create(const RtSceneDesc* d, RtScene** out) {
   HIP_TRY(hipHostMalloc((void**)&sc->countersHost, sizeof(Counters) * kCounterBlocks, hipHostMallocDefault));
   if (const char* e = std::getenv("RT_AMD_LEVEL_SYNC")) sc->levelSyncMode = std::atoi(e) != 0 ? 1 : 0;
   if (const char* e = std::getenv("RT_AMD_FUSED_HIT")) sc->fusedHit = std::atoi(e) != 0;
+  if (const char* e = std::getenv("RT_AMD_LAUNCH_EVENTS")) sc->launchEvents = std::atoi(e) != 0;
   HIP_TRY(hipEventCreate(&sc->evStart));
   HIP_TRY(hipEventCreate(&sc->evStop));
   DevScene& D = sc->dev;
@@ -2509,6 +2561,10 @@ int rt_render(RtScene* sc, const RtRenderParams* rp, unsigned char* rgb8_out, in
   fm.aaN = (rp->aa_mode == RT_AA_FULL) ? rp->aa_samples : 0;
   fm.jitter = (rp->aa_mode != RT_AA_NONE && rp->jitter) ? sc->jitterDev : nullptr;
   setDivisors(fm);
+  {
+    const int rc = uploadPixelCoordinates(sc, w, h, fm);
+    if (rc != RT_OK) return rc;
+  }
 
   sc->eventsUsed = 0;
   HIP_TRY(hipEventRecord(sc->evStart, sc->stream));
@@ -2654,6 +2710,8 @@ int rt_render_pixels(RtScene* sc, const RtRenderParams* rp, int n_pixels, const 
   fm.aaN = (rp->aa_mode == RT_AA_NONE) ? 0 : rp->aa_samples;
   fm.jitter = (rp->aa_mode != RT_AA_NONE && rp->jitter) ? sc->jitterDev : nullptr;
   setDivisors(fm);
+  rc = uploadPixelCoordinates(sc, rp->width, rp->height, fm);
+  if (rc != RT_OK) return rc;
   sc->eventsUsed = 0;
   HIP_TRY(hipEventRecord(sc->evStart, sc->stream));
   rc = renderRange(cx, 0, n_pixels);

@@ -3,6 +3,7 @@ measured on a single GPU (shard 0 of N, device output, no gather): the compute
 side of strong scaling, i.e. how much of a rank's time is fixed cost."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("RT_AMD_LAUNCH_EVENTS", "1")
 import torch
 import bench
 from raytracer_amd import abi, device, host, parallel
