@@ -74,7 +74,12 @@ def cpu_baseline(hs, width, height, kw, budget_s):
     CommandLineUI::run) on a bounded, evenly spread pixel sample of the same frame."""
     from raytracer_amd import host
     from oracle import loader
-    cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
+    # every host core this process may run on (OMP_NUM_THREADS, where the box sets one, is its share of the machine)
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or avail
     p, keep = host.render_params(width, height, **kw)
     npx = width * height
     stride = 7919 * 13 + 1  # spreads the sample over the whole frame
@@ -94,8 +99,42 @@ def cpu_baseline(hs, width, height, kw, budget_s):
     rays = st.rays_total
     return {"value": round(rays / dt / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
             "ms_per_step_extrapolated": round(1000.0 * dt * npx / count, 1),
+            "cores_available": avail,
             "sample": "%d of %d pixels (every %d-th, %d rays) of the same frame in %.1f s, "
-                      "reference KD traversal, %d std::threads" % (count, npx, stride, rays, dt, cores)}
+                      "reference KD traversal, %d std::threads (%s)" % (
+                          count, npx, stride, rays, dt, cores,
+                          "OMP_NUM_THREADS" if os.environ.get("OMP_NUM_THREADS") else "all cores the process may use")}
+
+
+def csrc_hash():
+    """Hash of the device sources: a committed counter pass belongs to the kernels it was taken on."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "raytracer_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        h.update(f.encode())
+        h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def kd_reference_rate(ds, hs, width, height, kw, count=20000):
+    """The caller's KD-tree walked with Scene::intersectKdTree's own rules
+    (traversal = reference) on a stratified subset of the same frame: Mrays/s of
+    that mode, outside the timed region (the timed frames use the library's BVH)."""
+    from raytracer_amd import abi, host
+    gy = max(1, int(round((count * height / float(width)) ** 0.5)))
+    gx = max(1, count // gy)
+    xs = (np.arange(gx) * width // gx + width // (2 * gx)).astype(np.int32)
+    ys = (np.arange(gy) * height // gy + height // (2 * gy)).astype(np.int32)
+    xy = np.stack(np.meshgrid(xs, ys, indexing="xy"), axis=-1).reshape(-1, 2).astype(np.int32)
+    p, keep = host.render_params(width, height, traversal=abi.RT_TRAVERSE_REFERENCE, **kw)
+    ds.render_pixels(p, xy[:256])                      # pool and kernels warm
+    t0 = time.perf_counter()
+    _, st = ds.render_pixels(p, xy)
+    dt = time.perf_counter() - t0
+    return {"Mrays_per_s": round(st.rays_total / dt / 1e6, 2), "rays": int(st.rays_total), "pixels": int(len(xy)),
+            "ms": round(dt * 1e3, 1),
+            "subset": "%d x %d grid of pixels over the frame, same depth and anti-aliasing" % (gx, gy)}
 
 
 def main():
@@ -252,7 +291,12 @@ def main():
             per_launch = flops_frame * args.steps / max(n, 1.0)
             ms_launch = ms / max(n, 1.0)
             ach = per_launch / (ms_launch * 1e-3) / 1e12 if ms_launch > 0 else 0.0
+            f64_only = (90.0 * t + 40.0 * o) * args.steps / max(n, 1.0) / (ms_launch * 1e-3) / 1e12 if ms_launch > 0 else 0.0
             return {"flop_per_ray": round(flops_frame / max(r, 1.0), 1), "achieved_TFLOPs": round(ach, 4),
+                    # the box steps (8 V) run in binary32 on the fast path; triangle and object tests in binary64
+                    "binary64_flop_per_ray": round((90.0 * t + 40.0 * o) / max(r, 1.0), 1),
+                    "box_step_flop_per_ray": round(8.0 * v / max(r, 1.0), 1),
+                    "frac_of_fp64_valu_peak_binary64_terms_only": round(f64_only / FP64_VALU_PEAK_TFLOPS, 4),
                     "frac_of_fp64_valu_peak": round(ach / FP64_VALU_PEAK_TFLOPS, 4),
                     "flop_per_launch": round(per_launch), "ms_per_launch": round(ms_launch, 4),
                     "launches_per_step": round(n / args.steps, 1), "rays_per_step": round(r),
@@ -268,6 +312,8 @@ def main():
         if os.path.exists(tpath) and args.scale == 1.0 and world == 1 and args.traversal == "fast":
             try:
                 tj = json.load(open(tpath))
+                if tj.get("csrc_sha") != csrc_hash():
+                    raise ValueError("counter pass taken on other kernels")
                 traffic = tj.get("k_trace_hbm_bytes_per_launch")
                 gbs = traffic / (kt["ms_per_launch"] * 1e-3) / 1e9 if traffic and kt["ms_per_launch"] > 0 else None
                 hbm = {"bytes_per_launch_from_counters": traffic,
@@ -276,21 +322,30 @@ def main():
                        "source": tj.get("source"), "measured_at_commit": tj.get("commit"),
                        "counter_pass": {k: tj.get(k) for k in ("k_trace_valu_busy", "k_trace_lanes_active",
                                                                "k_trace_waves_per_simd")}}
-            except Exception:
-                traffic, hbm = None, None
+            except Exception as e:
+                # no bytes rather than the bytes of other kernels
+                traffic, hbm = None, {"stale": str(e), "file": "profiles/traffic_%s.json" % args.config}
         roof = {"bound": "fp64_valu",
                 "kernel": "k_trace (%s)" % ("closest hit on the library's 4-wide BVH" if args.traversal == "fast"
                                             else "reference KD traversal"),
                 "achieved": kt["achieved_TFLOPs"], "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": kt["frac_of_fp64_valu_peak"], "traffic": traffic,
-                "note": "FP64 VALU, contraction off; algorithmic operations 8 V + 90 T + 40 O per ray from the "
-                        "in-run counter pass, launch durations from HIP events of the timed steps; traffic = HBM "
-                        "bytes per launch from the committed counter pass named under hbm",
+                "note": "FP64 VALU, contraction off; algorithmic operations 8 V + 90 T + 40 O per ray (the reference's "
+                        "binary64 cost of what was tested) from the in-run counter pass, launch durations from HIP "
+                        "events of the timed steps.  On the fast path only 90 T + 40 O run in binary64 -- the box "
+                        "steps 8 V are binary32 packed multiply-adds -- see frac_of_fp64_valu_peak_binary64_terms_only. "
+                        "traffic = HBM bytes per launch from the committed counter pass named under hbm",
                 "hbm": hbm, "k_trace": kt, "k_shadow": kl}
 
     if rank == 0:
         if args.out:
             host.write_bmp(args.out, frame.cpu().numpy())
+        kd_ref = None
+        if world == 1 and args.traversal == "fast" and not args.no_stats_pass:
+            try:
+                kd_ref = kd_reference_rate(ds, hs, width, height, kw)
+            except Exception as e:   # a number for orientation, never a reason to lose the line
+                kd_ref = {"error": str(e)}
         cpu = None
         if args.cpu_seconds > 0 and world == 1:   # the CPU leg belongs to the single-GPU line only
             cpu = cpu_baseline(hs, width, height, kw, args.cpu_seconds)
@@ -308,6 +363,7 @@ def main():
                        "traversal": ("fast: 4-wide BVH built by the library at scene creation; the caller's KD-tree is "
                                      "uploaded but not traversed" if args.traversal == "fast"
                                      else "reference: the caller's KD-tree, Scene::intersectKdTree's rules"),
+                       "kd_reference": kd_ref,
                        "tile": TILE, "rccl_ranks": world if use_dist else 0, "phases_per_step": phases,
                        "rays_per_step": round(total_rays / args.steps),
                        "sharding": "interleaved %dx%d tiles over %d rank(s), one gather per frame" % (TILE, TILE, world),

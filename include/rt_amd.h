@@ -226,7 +226,9 @@ int rt_render(RtScene* scene, const RtRenderParams* params,
 
 /* Scene::intersect for n rays given as 6 doubles (p, d) each. Host pointers.
  * Stages through a device buffer kept in the scene handle, which grows (one
- * hipMalloc) when a call brings more rays than any before it. */
+ * hipMalloc) when a call brings more rays than any before it.  Like every call
+ * that takes a handle: one caller at a time per handle (calls on the same
+ * handle from two threads share its staging buffer, streams and ray pool). */
 int rt_intersect_batch(RtScene* scene, int traversal, int n, const double* rays_pd,
                        const int* ray_types, RtHit* hits);
 
@@ -270,6 +272,13 @@ int rt_render_pixels(RtScene* scene, const RtRenderParams* params, int n_pixels,
  * on a host RGB8 frame; mask_out gets 255 / 0 per pixel. */
 int rt_edge_mask(const unsigned char* rgb8, int width, int height, int cutoff,
                  unsigned char* mask_out);
+
+/* Test hook: out[i] = x[i] ^ (n + delta) as the shading kernels compute the
+ * powers of Material::shade and SpotLight::shadowAttenuation
+ * (src/scene/material.cpp:72, src/scene/light.cpp:147) when every exponent of a
+ * scene is a small non-negative integer n up to a rounding residue delta
+ * (|delta| <= 1e-12).  Host pointers. */
+int rt_test_pow_near_int(int count, const double* x, int n, double delta, double* out);
 
 const char* rt_last_error(void);
 int rt_abi_version(void);

@@ -968,10 +968,15 @@ k_shade(DevScene S, int items, int par, RaySrc R, int depthLeft, Pool P) {
 #ifndef RT_HIT_WAVES
 #define RT_HIT_WAVES 5
 #endif
+// Entries per thread of k_hit's tiles: the primitive and the face word of every
+// entry wait in LDS between the two passes (2 x 4 bytes x kBlock per entry).
+constexpr int kHitItems = 8;
+
 __global__ void __launch_bounds__(kBlock, RT_HIT_WAVES)
 k_hit(DevScene S, int items, int par, RaySrc R, int level, int depthLeft, int blackMiss, long long traced, Pool P) {
   __shared__ TileScan tsHit, tsRefl;
   __shared__ unsigned int litCount;
+  __shared__ int heldPrim[kHitItems][kBlock], heldInfo[kHitItems][kBlock];
   const long long n = tracedRays(P.counters, traced);
   const size_t rayOff = P.counters->rayOff, spOff = P.counters->spOff;
   const size_t nextRayOff = rayOff + (size_t)n;
@@ -979,18 +984,21 @@ k_hit(DevScene S, int items, int par, RaySrc R, int level, int depthLeft, int bl
   checkCoverage(P.counters, gridDim.x * perTile, n);
   const long long tileBase = blockIdx.x * perTile;
   if (tileBase >= n) return;   // whole block, uniform
-  // pass 1: which rays hit, which of the hits reflect, how many are lit
+  // pass 1: which rays hit, which of the hits reflect, how many are lit.  Every
+  // entry's loads are independent of the other entries': the loop is unrolled
+  // so that they are in flight together.
   unsigned int hitMask = 0, reflMask = 0, myLit = 0;
-  for (int k = 0; k < items; k++) {
+#pragma unroll
+  for (int k = 0; k < kHitItems; k++) {
+    if (k >= items) break;
     const long long i = tileBase + k * kBlock + threadIdx.x;
     const int prim = i < n ? P.hitPrim[i] : RT_PRIM_NONE;
     const bool hit = prim != RT_PRIM_NONE;
-    bool refl = false;
-    if (hit) {
-      const int info = S.faceInfo[prim & ~RT_PRIM_FACE];
-      if (info & RT_FI_LIT) myLit++;
-      refl = depthLeft > 0 && (S.devMats[info & RT_FI_MATERIAL].flags & RT_MATF_KR) != 0;
-    }
+    const int info = hit ? S.faceInfo[prim & ~RT_PRIM_FACE] : 0;
+    heldPrim[k][threadIdx.x] = prim;
+    heldInfo[k][threadIdx.x] = info;
+    if (info & RT_FI_LIT) myLit++;
+    const bool refl = depthLeft > 0 && ((unsigned int)info & RT_FI_REFLECTS) != 0;
     hitMask |= (hit ? 1u : 0u) << k;
     reflMask |= (refl ? 1u : 0u) << k;
     tileCount(tsHit, 0, k, hit);
@@ -1030,12 +1038,13 @@ k_hit(DevScene S, int items, int par, RaySrc R, int level, int depthLeft, int bl
       P.counters->overflow = RT_OVERFLOW_POOL;
       continue;
     }
-    const int fi = P.hitPrim[i] & ~RT_PRIM_FACE;
-    const int info = S.faceInfo[fi];
+    const int fi = heldPrim[k][threadIdx.x] & ~RT_PRIM_FACE;
+    const int info = heldInfo[k][threadIdx.x];
+    const double t = P.hitT[i];
     const RayPD ray = rayAt(S, R, (int)i);
     Surface sf;
     surfaceNormalOfFace(S, fi, info, ray.p, ray.d, sf);
-    const V3 Q = ray.p + (P.hitT[i] * ray.d);                            // ray::at (ray.h:42-43)
+    const V3 Q = ray.p + (t * ray.d);                            // ray::at (ray.h:42-43)
     if (level > 0) P.spRayGlobal[g] = (int)(rayOff + i);   // for k_combine, which level 0 does not go through
     P.spMat[g] = (int)((unsigned int)(info & RT_FI_MATERIAL) | ((info & RT_FI_LIT) ? RT_SPM_LIT : 0u));   // material.cpp:50-53
     if (level == 0 && firstSampleOfPixel(R.fm, i)) P.primaryId[i] = sf.objectID;
@@ -1190,6 +1199,13 @@ k_intersect(DevScene S, int n, const double* rays, const int* types, RtHit* hits
     h.object_id = sf.objectID;
   }
   hits[i] = h;
+}
+
+// powNearInt on a list of bases (test hook, rt_test_pow_near_int)
+__global__ void __launch_bounds__(kBlock)
+k_pow_near_int(int count, const double* x, int n, double delta, double* out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) out[i] = powNearInt(x[i], n, delta);
 }
 
 // Packed tiles -> full frame
@@ -1789,7 +1805,9 @@ int renderBatch(RenderCtx& cx, long long first, int count, long long* slotsUsed,
     // nothing to show behind a ray that hits nothing, and no coefficient that would turn a zero into a NaN
     const int blackMiss = (!(rp.use_cubemap && sc->dev.cube_w > 0) && sc->finiteCoefficients) ? 1 : 0;
     if (fused) {
-      k_hit<<<tiles, kBlock, 0, sc->stream>>>(sc->dev, items, par, R, level, rp.depth - level, blackMiss, traced, P);
+      const int hitItems = std::min(items, kHitItems);
+      k_hit<<<blocksFor(est, kBlock * hitItems), kBlock, 0, sc->stream>>>(sc->dev, hitItems, par, R, level, rp.depth - level,
+                                                                        blackMiss, traced, P);
     } else {
       k_classify<<<tiles, kBlock, 0, sc->stream>>>(items, level, R, blackMiss, traced, P);
       if (sc->hasFaces) k_surface<<<dense, kBlock, 0, sc->stream>>>(sc->dev, R, level, P);
@@ -2296,7 +2314,11 @@ int rt_scene_create(const RtSceneDesc* d, RtScene** out) {
       HIP_TRY(upload(reinterpret_cast<const DevBvhNode*>(wide.nodes.data()), wide.nodes.size(), &bn));
       keep(bn);
       D.bvh = bn;
-      {
+      D.bvhF = nullptr;
+      D.bvhLaneF = 0;
+      if (sc->triOnly) {
+        // (only the kernels of triangle-only scenes read this form: 1 KiB per
+        // node, sixteen times the quantised node array)
         // the same child boxes decoded to binary32 planes, outward rounded
         static_assert(sizeof(DevBvhNodeF) == 128, "float BVH node must be 128 bytes");
         // Eight copies per node, copy o for rays whose direction is negative on
@@ -2429,8 +2451,9 @@ int rt_scene_create(const RtSceneDesc* d, RtScene** out) {
       const RtMesh& M = d->meshes[mi];
       const RtMaterial& mat = d->materials[d->objects[M.object].material];
       auto nz = [](const double* v) { return !(v[0] == 0.0 && v[1] == 0.0 && v[2] == 0.0); };
-      const int word = d->objects[M.object].material | ((nz(mat.kd) || nz(mat.ks)) ? RT_FI_LIT : 0) |
-                       (M.has_vertex_normals ? RT_FI_VNORMALS : 0) | (M.has_vertex_materials ? RT_FI_VMATERIALS : 0);
+      const int word = (int)((unsigned int)d->objects[M.object].material | ((nz(mat.kd) || nz(mat.ks)) ? RT_FI_LIT : 0) |
+                             (M.has_vertex_normals ? RT_FI_VNORMALS : 0) | (M.has_vertex_materials ? RT_FI_VMATERIALS : 0) |
+                             (nz(mat.kr) ? RT_FI_REFLECTS : 0u));
       for (int f = 0; f < M.n_faces; f++) info[(size_t)M.first_face + f] = word;
     }
     int* p;
@@ -2822,6 +2845,18 @@ int rt_unpack_tiles(const unsigned char* packed_dev, int bytes_per_pixel, int wi
   k_unpack<<<gridFor(slots), kBlock, 0, st>>>(packed_dev, bytes_per_pixel, fm, off, TL.nTiles, frame_dev);
   HIP_TRY(hipGetLastError());
   return RT_OK;   // stream-ordered: the caller synchronises hip_stream
+}
+
+int rt_test_pow_near_int(int count, const double* x, int n, double delta, double* out) {
+  if (count < 0 || (count > 0 && (!x || !out)) || n < 0) return fail(RT_ERR_INVALID, "bad argument");
+  if (count == 0) return RT_OK;
+  DevBuf in, res;
+  HIP_TRY(in.allocCopy(x, (size_t)count * sizeof(double)));
+  HIP_TRY(res.alloc((size_t)count * sizeof(double)));
+  k_pow_near_int<<<gridFor(count), kBlock, 0, 0>>>(count, in.as<double>(), n, delta, res.as<double>());
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(out, res.p, (size_t)count * sizeof(double), hipMemcpyDeviceToHost));
+  return RT_OK;
 }
 
 int rt_edge_mask(const unsigned char* rgb8, int width, int height, int cutoff, unsigned char* mask_out) {

@@ -63,9 +63,15 @@ __device__ __forceinline__ V3 mul33(const double* m, const V3& v) {
 // The result is the correctly rounded power in practice (0 misses in 20 000
 // random cases against exact rational arithmetic, where the C library's pow
 // misses 19 by one unit in the last place).  Special cases as pow: y == 0 gives
-// 1 whatever x is; x == 0 gives 0; a negative x with delta != 0 gives NaN.
+// 1 whatever x is; x == 0 gives 0; a negative x with delta != 0 gives NaN; a
+// power beyond the binary64 range gives infinity, one below it 0.
 __device__ __forceinline__ void ddMul(double& ah, double& al, double bh, double bl) {
   const double p = ah * bh;
+  if (!(fabs(p) <= 1.7976931348623157e308)) {   // overflow (or NaN): no error term to form, fma(inf, ., -inf) is NaN
+    ah = p;
+    al = 0.0;
+    return;
+  }
   double e = __builtin_fma(ah, bh, -p);
   e = e + (ah * bl + al * bh);
   const double hi = p + e;
@@ -92,9 +98,15 @@ __device__ __forceinline__ double powNearInt(double x, int n, double delta) {
     ddMul(bh, bl, bh, bl);
   }
   if (delta != 0.0) {
-    // x < 0 with a fractional exponent: the logarithm is NaN, as pow's result
-    const double c = delta * (double)__logf((float)x);
-    rl = rl + rh * c;
+    // x < 0 with a fractional exponent: the logarithm is NaN, as pow's result.
+    // A positive x below binary32's range takes the logarithm of the smallest
+    // normal float (its power has underflowed to 0 long before, and 0 times a
+    // finite correction stays 0 where 0 * log(0) would be NaN); an overflowed
+    // power stays infinite.
+    float xf = (float)x;
+    if (x > 0.0 && xf < 1.17549435e-38f) xf = 1.17549435e-38f;
+    const double c = delta * (double)__logf(xf);
+    if (fabs(rh) <= 1.7976931348623157e308) rl = rl + rh * c;
   }
   return rh + rl;
 }

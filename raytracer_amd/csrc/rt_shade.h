@@ -120,6 +120,27 @@ __device__ __forceinline__ void surfaceNormalOfFace(const DevScene& S, int fi, i
   }
 }
 
+// surfaceNormalOfFace for a face of an identity-transform mesh whose record T
+// and corner normals fn (nine doubles; read only where the face has vertex
+// normals) the caller has already loaded: the same arithmetic, no memory
+// access in between.
+__device__ __forceinline__ void surfaceNormalLoaded(const DevScene& S, const DevTri& T, const double* fn, int info,
+                                                    const V3& p, const V3& d, Surface& sf) {
+  const bool smoothN = S.smooth && (info & RT_FI_VNORMALS);
+  sf.objectID = T.object_id;
+  V3 Nl = V3(T.n);
+  const double I4[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  if (smoothN) {
+    const LocalRay lr = toLocal(I4, p, d);
+    double rt;
+    V3 bary;
+    triTest<false>(T, lr.p, lr.d, false, rt, &bary);
+    Nl = (bary.x * V3(fn)) + (bary.y * V3(fn + 3)) + (bary.z * V3(fn + 6));
+  }
+  sf.N = normalized(mul33(I3, normalized(Nl)));
+}
+
 // Full isect of the winning primitive: what Geometry::intersect +
 // <Primitive>::intersectLocal left in `i` for the closest candidate
 // (scene.cpp:13-36; trimesh.cpp:173-204).  A null `mat` skips the material;

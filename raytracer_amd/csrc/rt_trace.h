@@ -105,6 +105,7 @@ struct DevMat {
 #define RT_FI_LIT 0x10000000      // the material's kd or ks is non-zero
 #define RT_FI_VNORMALS 0x20000000
 #define RT_FI_VMATERIALS 0x40000000
+#define RT_FI_REFLECTS 0x80000000u  // the material's kr is non-zero (RayTracer.cpp:161)
 
 struct DevScene {
   const DevMat* devMats;     // one per material

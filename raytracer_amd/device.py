@@ -137,3 +137,12 @@ def edge_mask(rgb, cutoff):
     out = np.zeros((h, w), dtype=np.uint8)
     _check(lib().rt_edge_mask(rgb.ctypes.data, w, h, cutoff, out.ctypes.data), "rt_edge_mask")
     return out
+
+
+def pow_near_int(x, n, delta):
+    """x ** (n + delta) the way the shading kernels raise to near-integer exponents (test hook)."""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    out = np.zeros_like(x)
+    _check(lib().rt_test_pow_near_int(len(x), x.ctypes.data_as(abi.PD), n, delta, out.ctypes.data_as(abi.PD)),
+           "rt_test_pow_near_int")
+    return out

@@ -449,3 +449,31 @@ def test_near_integer_exponents_without_the_general_power(built, monkeypatch):
         ds.close()
         common.assert_parity(rgb, hits, ref_rgb, ref_hits, what="RT_AMD_INT_POW=" + setting)
         assert _ray_counts(st) == _ray_counts(ref_st)
+
+
+def test_integer_powers_in_double_double(built):
+    """powNearInt against the C library's pow: within one unit in the last place on
+    ordinary arguments, and pow's own answers where the power leaves the binary64
+    range or the base lies below binary32's (0, infinity -- not NaN)."""
+    rng = np.random.RandomState(11)
+    x = np.concatenate([rng.uniform(0.0, 1.0, 4000), rng.uniform(0.9, 1.1, 1000)])
+    for n, delta in ((1, 0.0), (6, 0.0), (32, -3.552713678800501e-15), (40, 0.0), (128, -1.4210854715202004e-14)):
+        assert float(n) + delta != float(n) or delta == 0.0   # the exponent n + delta is a binary64 number
+        got = device.pow_near_int(x, n, delta)
+        ref = np.power(x, n + delta)
+        ulp = np.spacing(ref)
+        assert np.all(np.abs(got - ref) <= ulp), (n, delta, np.abs((got - ref) / ulp).max())
+    # the power underflows, base below the smallest normal float: 0, as pow says
+    tiny = np.array([1.0e-40, 3.0e-39, 1.0e-300, 4.9e-324])
+    assert np.array_equal(device.pow_near_int(tiny, 32, -3.552713678800501e-15), np.zeros(4))
+    assert np.array_equal(device.pow_near_int(tiny, 2, 0.0), np.power(tiny, 2))
+    # the power overflows: infinity
+    big = np.array([10.0, 1.0e100, 1.06])
+    assert np.all(np.isposinf(device.pow_near_int(big[:2], 400, 0.0)))
+    assert np.all(np.isposinf(device.pow_near_int(big[:2], 400, 1.0e-13)))
+    assert np.isposinf(device.pow_near_int(big[2:], 20000, 0.0)[0])
+    # pow's special cases
+    assert device.pow_near_int(np.array([0.0, 5.0, np.nan]), 0, 0.0).tolist() == [1.0, 1.0, 1.0]
+    assert device.pow_near_int(np.array([0.0]), 3, 0.0)[0] == 0.0
+    assert np.isnan(device.pow_near_int(np.array([-2.0]), 3, 1.0e-13)[0])
+    assert device.pow_near_int(np.array([-2.0]), 3, 0.0)[0] == -8.0

@@ -61,3 +61,25 @@ def test_static_staging_across_two_scenes_on_one_device(built):
         assert _same(ds.intersect_static(rays, types, abi.RT_TRAVERSE_FAST), ds.intersect(rays, types, abi.RT_TRAVERSE_FAST), 2000)
     a.close()
     b.close()
+
+
+def test_static_entry_point_allocates_nothing(built):
+    """The entry point's one contract: on a handle that has never gone through
+    rt_intersect_batch (whose staging buffer lives in the handle), a series of
+    calls of every size leaves the device's free memory where it was."""
+    import torch
+    rng = np.random.RandomState(31)
+    hs = host.HostScene(text=common.small_mesh_scene(3))
+    ds = device.DeviceScene(hs.desc_ptr)
+    rays, types = _rays(rng, 65536)
+    ds.intersect_static(rays[:64], types[:64], abi.RT_TRAVERSE_FAST)   # code objects, queues: loaded before the baseline
+    ds.intersect_static(rays[:64], types[:64], abi.RT_TRAVERSE_REFERENCE)
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for n in (65536, 40000, 9000, 65536, 1):
+        for trav in (abi.RT_TRAVERSE_FAST, abi.RT_TRAVERSE_REFERENCE):
+            got = ds.intersect_static(rays[:n], types[:n], trav)
+            assert len(got) == n
+            free, _ = torch.cuda.mem_get_info()
+            assert free == free0, "device memory moved by %d bytes in a call of %d rays" % (free0 - free, n)
+    ds.close()

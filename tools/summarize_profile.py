@@ -101,7 +101,9 @@ def main():
             commit += "+uncommitted"
     except Exception:
         commit = None
-    out = {"source": "profiles/%s_pmc_summary.md" % tag, "commit": commit, "kernels": traffic}
+    sys.path.insert(0, ROOT)
+    import bench
+    out = {"source": "profiles/%s_pmc_summary.md" % tag, "commit": commit, "csrc_sha": bench.csrc_hash(), "kernels": traffic}
     if kt:
         out["k_trace_waves_per_simd"] = kt["waves_per_simd"]
         out["k_trace_hbm_bytes_per_launch"] = kt["read_bytes_per_launch"] + kt["write_bytes_per_launch"]
