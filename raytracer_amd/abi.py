@@ -118,6 +118,15 @@ RT_AMD_SYMBOLS = {
     "rt_abi_version": (C.c_int, []),
 }
 
+# Every symbol include/rt_multi.h declares (librt_multi.so: host threads + RCCL over the C-ABI above).
+RT_MULTI_SYMBOLS = {
+    "rt_multi_create": (C.c_int, [C.POINTER(RtSceneDesc), C.c_int, PI, C.POINTER(C.c_void_p)]),
+    "rt_multi_render": (C.c_int, [C.c_void_p, C.POINTER(RtRenderParams), C.c_void_p, C.POINTER(RtStats)]),
+    "rt_multi_destroy": (None, [C.c_void_p]),
+    "rt_multi_device_count": (C.c_int, [C.c_void_p]),
+    "rt_multi_last_error": (C.c_char_p, []),
+}
+
 RT_HOST_SYMBOLS = {
     "rth_default_options": (None, [C.POINTER(RthOptions)]),
     "rth_scene_parse": (C.c_void_p, [C.c_char_p, C.c_char_p, C.POINTER(RthOptions), C.c_char_p, C.c_int]),

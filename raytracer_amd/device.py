@@ -37,6 +37,21 @@ def lib():
     return _LIB
 
 
+_MULTI = None
+
+
+def multi_lib():
+    """librt_multi.so: a frame over several GPUs of one node from C / C++ (include/rt_multi.h)."""
+    global _MULTI
+    if _MULTI is None:
+        lib()   # the HIP runtime and librt_amd.so first, so that both libraries share them
+        path = os.path.join(_HERE, "librt_multi.so")
+        if not os.path.exists(path):
+            raise DeviceError("librt_multi.so is not built; run `python -c 'import __graft_entry__ as g; g.build()'`")
+        _MULTI = abi.bind(C.CDLL(path), abi.RT_MULTI_SYMBOLS)
+    return _MULTI
+
+
 def _check(rc, what):
     if rc != 0:
         raise DeviceError("%s failed (%d): %s" % (what, rc, lib().rt_last_error().decode()))
@@ -146,3 +161,30 @@ def pow_near_int(x, n, delta):
     _check(lib().rt_test_pow_near_int(len(x), x.ctypes.data_as(abi.PD), n, delta, out.ctypes.data_as(abi.PD)),
            "rt_test_pow_near_int")
     return out
+
+
+class MultiScene:
+    """RtMulti handle: the scene on several GPUs of this node, one frame per call."""
+
+    def __init__(self, desc_ptr, n_devices, device_ids=None):
+        self._h = C.c_void_p()
+        ids = None
+        if device_ids is not None:
+            ids = (C.c_int * n_devices)(*device_ids)
+        rc = multi_lib().rt_multi_create(desc_ptr, n_devices, ids, C.byref(self._h))
+        if rc != 0:
+            raise DeviceError("rt_multi_create failed (%d): %s" % (rc, multi_lib().rt_multi_last_error().decode()))
+
+    def render(self, params):
+        h, w = params.height, params.width
+        rgb = np.zeros((h, w, 3), dtype=np.uint8)
+        st = abi.RtStats()
+        rc = multi_lib().rt_multi_render(self._h, C.byref(params), rgb.ctypes.data, C.byref(st))
+        if rc != 0:
+            raise DeviceError("rt_multi_render failed (%d): %s" % (rc, multi_lib().rt_multi_last_error().decode()))
+        return rgb, st
+
+    def close(self):
+        if getattr(self, "_h", None):
+            multi_lib().rt_multi_destroy(self._h)
+            self._h = None

@@ -9,7 +9,9 @@
 // Extra switches (not in the reference): --reference-traversal walks the
 // reference's KD-trees with its exact rules instead of the library's BVH;
 // --aa N renders N x N jittered samples per pixel (tracePixelAntiAlias);
-// --threshold T with --aa selects the GUI's adaptive mode.
+// --threshold T with --aa selects the GUI's adaptive mode; --gpus N spreads the
+// frame over N GPUs of the node (one host thread per GPU where the reference
+// has one per column strip, include/rt_multi.h).
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -20,6 +22,7 @@
 #include <vector>
 
 #include "../../include/rt_amd.h"
+#include "../../include/rt_multi.h"
 #include "host_api.h"
 
 namespace {
@@ -32,7 +35,7 @@ void usage(const char* prog, int depth, int size) {
 
 int main(int argc, char** argv) {
   int depth = 2, size = 512;  // TraceUI defaults (src/ui/TraceUI.h:21)
-  int aa = 0, threshold = -1;
+  int aa = 0, threshold = -1, gpus = 0;
   bool referenceTraversal = false;
   std::vector<std::string> files;
   for (int i = 1; i < argc; i++) {
@@ -41,6 +44,7 @@ int main(int argc, char** argv) {
     else if (a == "-w" && i + 1 < argc) size = std::atoi(argv[++i]);
     else if (a == "--aa" && i + 1 < argc) aa = std::atoi(argv[++i]);
     else if (a == "--threshold" && i + 1 < argc) threshold = std::atoi(argv[++i]);
+    else if (a == "--gpus" && i + 1 < argc) gpus = std::atoi(argv[++i]);
     else if (a == "--reference-traversal") referenceTraversal = true;
     else if (!a.empty() && a[0] == '-') {
       std::cerr << "Invalid argument: '" << a << "'." << std::endl;
@@ -64,8 +68,18 @@ int main(int argc, char** argv) {
   const int width = size;
   const int height = (int)(width / rth_scene_aspect_ratio(hs) + 0.5);
 
+  if (gpus < 0 || (gpus > 0 && aa > 0 && threshold >= 0)) {
+    std::cerr << "--gpus takes a positive count and does not go with --threshold" << std::endl;
+    return 1;
+  }
   RtScene* scene = nullptr;
-  if (rt_scene_create(rth_scene_desc(hs), &scene) != RT_OK) {
+  RtMulti* multi = nullptr;
+  if (gpus > 0) {
+    if (rt_multi_create(rth_scene_desc(hs), gpus, nullptr, &multi) != RT_OK) {
+      std::cerr << "rt_multi_create: " << rt_multi_last_error() << std::endl;
+      return 1;
+    }
+  } else if (rt_scene_create(rth_scene_desc(hs), &scene) != RT_OK) {
     std::cerr << "rt_scene_create: " << rt_last_error() << std::endl;
     return 1;
   }
@@ -90,7 +104,12 @@ int main(int argc, char** argv) {
   std::vector<unsigned char> buf((size_t)width * height * 3);
   RtStats st;
   const auto t0 = std::chrono::steady_clock::now();
-  if (rt_render(scene, &p, buf.data(), nullptr, &st) != RT_OK) {
+  if (multi) {
+    if (rt_multi_render(multi, &p, buf.data(), &st) != RT_OK) {
+      std::cerr << "rt_multi_render: " << rt_multi_last_error() << std::endl;
+      return 1;
+    }
+  } else if (rt_render(scene, &p, buf.data(), nullptr, &st) != RT_OK) {
     std::cerr << "rt_render: " << rt_last_error() << std::endl;
     return 1;
   }
@@ -101,7 +120,8 @@ int main(int argc, char** argv) {
   }
   const unsigned long long rays = st.rays_primary + st.rays_reflect + st.rays_refract + st.rays_shadow;
   std::cout << "total time = " << t << " seconds, rays traced = " << rays << std::endl;
-  rt_scene_destroy(scene);
+  if (multi) rt_multi_destroy(multi);
+  if (scene) rt_scene_destroy(scene);
   rth_scene_free(hs);
   return 0;
 }

@@ -24,6 +24,16 @@ def test_rt_amd_exports_every_declared_symbol(built):
     assert lib.rt_abi_version() == abi.RT_AMD_ABI_VERSION
 
 
+def test_rt_multi_exports_every_declared_symbol(built):
+    declared = _declared_functions("include/rt_multi.h")
+    assert declared == set(abi.RT_MULTI_SYMBOLS), declared ^ set(abi.RT_MULTI_SYMBOLS)
+    lib = device.multi_lib()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.rt_multi_device_count(None) == 0
+    assert lib.rt_multi_create(None, 1, None, None) == -1 and b"bad argument" in lib.rt_multi_last_error()
+
+
 def test_host_exports_every_declared_symbol(built):
     declared = _declared_functions("raytracer_amd/host/host_api.h")
     assert declared == set(abi.RT_HOST_SYMBOLS), declared ^ set(abi.RT_HOST_SYMBOLS)
