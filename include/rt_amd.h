@@ -268,6 +268,33 @@ int rt_unpack_tiles(const unsigned char* packed_dev, int bytes_per_pixel,
 int rt_render_pixels(RtScene* scene, const RtRenderParams* params, int n_pixels, const int* xy,
                      unsigned char* rgb8_out, RtStats* stats_out);
 
+/* The second pass of GraphicalUI::doAntiAliasing (src/ui/GraphicalUI.cpp:377-435)
+ * for one rank of a frame that is sharded over several GPUs, without the frame
+ * leaving the device: base_rgb_dev is the COMPLETE base image (width * height *
+ * 3 bytes, row 0 = bottom row) in this device's memory -- every rank holds the
+ * same one after the all-gather of the base pass.  The call builds the edge
+ * mask (applyFilter, :437-486, cutoff params->aa_threshold) and the list of
+ * flagged pixels in the reference's row-by-row order on the device, takes
+ * entries share_index, share_index + share_count, ... of it, and renders them
+ * with aa_samples x aa_samples jittered samples (tracePixelAntiAlias) into
+ * rows_dev: 3 bytes per pixel of the share, in list order (device memory, room
+ * for rows_capacity pixels).  *n_flagged: pixels flagged in the whole frame (the
+ * same on every rank); *n_rendered: this share's part.  The caller makes sure
+ * that whatever wrote base_rgb_dev has finished.  Mask and list live in buffers
+ * the handle keeps; the list stays valid for rt_patch_flagged until the next
+ * call that builds one (this one, or rt_render in adaptive mode). */
+int rt_render_flagged(RtScene* scene, const RtRenderParams* params, const unsigned char* base_rgb_dev,
+                      int share_index, int share_count, unsigned char* rows_dev, long long rows_capacity,
+                      long long* n_flagged, long long* n_rendered, RtStats* stats_out);
+
+/* Writes the re-rendered pixels of share share_index of share_count (rows_dev,
+ * as rt_render_flagged of that share left them -- on this or another rank) over
+ * their places in frame_dev, a full frame in this device's memory, using the
+ * flagged list the handle built last.  Ordered on hip_stream, returns without
+ * waiting (GraphicalUI.cpp:357-375 overwrites the buffer's pixels in place). */
+int rt_patch_flagged(RtScene* scene, int share_index, int share_count, const unsigned char* rows_dev,
+                     unsigned char* frame_dev, void* hip_stream);
+
 /* Laplacian edge mask of GraphicalUI::applyFilter (ui/GraphicalUI.cpp:437-486)
  * on a host RGB8 frame; mask_out gets 255 / 0 per pixel. */
 int rt_edge_mask(const unsigned char* rgb8, int width, int height, int cutoff,

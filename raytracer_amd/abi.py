@@ -113,6 +113,9 @@ RT_AMD_SYMBOLS = {
     "rt_unpack_tiles": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                   C.c_int, C.c_void_p, C.c_void_p]),
     "rt_edge_mask": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "rt_render_flagged": (C.c_int, [C.c_void_p, C.POINTER(RtRenderParams), C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                   C.c_longlong, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(RtStats)]),
+    "rt_patch_flagged": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rt_test_pow_near_int": (C.c_int, [C.c_int, PD, C.c_int, C.c_double, PD]),
     "rt_last_error": (C.c_char_p, []),
     "rt_abi_version": (C.c_int, []),

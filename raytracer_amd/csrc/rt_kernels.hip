@@ -167,6 +167,7 @@ struct FrameMap {           // pixel slot -> pixel, for tile-ordered rendering
   int shardIndex, shardCount;
   const int* pixelList;     // optional explicit (x,y) list (adaptive AA), else NULL
   int listOutput;           // with pixelList: 1 = the output is indexed by list position, 0 = by frame position
+  int listFirst, listStride;   // pixel slot k is entry listFirst + k * listStride of the list (a share of it)
   int ns;                   // samples per pixel
   int aaN;                  // n (ns = n*n) or 0
   const double* jitter;     // device copy, 2*ns values or NULL
@@ -211,7 +212,7 @@ inline SlotBase makeSlotBase(const FrameMap& fm, long long slot) {
 __device__ __forceinline__ bool slotToPixel(const FrameMap& fm, const SlotBase& base, unsigned int rel, int& x, int& y,
                                             int& tileK, int& lx, int& ly) {
   if (fm.pixelList) {
-    const long long slot = base.slot + rel;
+    const long long slot = fm.listFirst + (base.slot + rel) * (long long)fm.listStride;
     x = fm.pixelList[2 * slot];
     y = fm.pixelList[2 * slot + 1];
     tileK = 0; lx = ly = 0;
@@ -1311,6 +1312,20 @@ k_flag_write(const unsigned char* mask, int w, long long n, const unsigned int* 
   xy[2 * (size_t)slot + 1] = (int)(i / w);
 }
 
+// Entries first, first + stride, ... of an (x, y) list take the colours of
+// rows 0, 1, ... (the re-rendered pixels of one share, GraphicalUI.cpp:405-425).
+__global__ void __launch_bounds__(kBlock)
+k_patch_listed(const int* xy, long long first, long long stride, long long n, const unsigned char* rows, int w,
+               unsigned char* frame) {
+  const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const long long e = first + k * stride;
+  const size_t o = (size_t)xy[2 * e] + (size_t)xy[2 * e + 1] * w;
+  frame[3 * o + 0] = rows[3 * k + 0];
+  frame[3 * o + 1] = rows[3 * k + 1];
+  frame[3 * o + 2] = rows[3 * k + 2];
+}
+
 }  // namespace
 
 // ================================================================ host side
@@ -1430,6 +1445,13 @@ struct RtScene {
   double* pixelXY = nullptr; int pixelXYw = 0, pixelXYh = 0;   // i / width per column, then j / height per row
   std::vector<double> pixelXYHost;
   unsigned char* isectBuf = nullptr; size_t isectCap = 0;   // rt_intersect_batch's staging, in rays
+  // adaptive anti-aliasing: edge mask, flagged pixels per run of kBlock pixels, the (x, y) list of the flagged
+  // pixels of the last base image (and whose it was)
+  unsigned char* flagMask = nullptr; size_t flagMaskCap = 0;
+  unsigned int* flagRuns = nullptr; size_t flagRunsCap = 0;
+  int* flagList = nullptr; size_t flagListCap = 0;
+  long long flagCount = 0; int flagW = 0, flagH = 0;
+  unsigned char* listStage = nullptr; size_t listStageCap = 0;   // rt_render_pixels: the caller's list and its colours
   std::vector<hipEvent_t> events;  // pairs around traversal kernels
   size_t eventsUsed = 0;
   std::vector<unsigned char> eventKind;   // per pair: 0 k_trace, 1 k_lights
@@ -1459,6 +1481,10 @@ struct RtScene {
     if (jitterDev) hipFree(jitterDev);
     if (pixelXY) hipFree(pixelXY);
     if (isectBuf) hipFree(isectBuf);
+    if (flagMask) hipFree(flagMask);
+    if (flagRuns) hipFree(flagRuns);
+    if (flagList) hipFree(flagList);
+    if (listStage) hipFree(listStage);
     for (hipEvent_t e : events) hipEventDestroy(e);
     if (countersHost) hipHostFree(countersHost);
     if (evStart) hipEventDestroy(evStart);
@@ -2011,6 +2037,57 @@ int uploadJitter(RtScene* sc, const RtRenderParams* rp, int ns) {
   HIP_TRY(hipStreamSynchronize(sc->stream));   // the staging vector below may still be read by an earlier copy
   sc->jitterHost.assign(rp->jitter, rp->jitter + need);
   HIP_TRY(hipMemcpyAsync(sc->jitterDev, sc->jitterHost.data(), need * sizeof(double), hipMemcpyHostToDevice, sc->stream));
+  return RT_OK;
+}
+
+// Grows a device buffer that lives in the scene handle (contents are not kept).
+template <class T>
+int growBuffer(T** buf, size_t* cap, size_t need) {
+  if (*cap >= need) return RT_OK;
+  if (*buf) (void)hipFree(*buf);
+  *buf = nullptr;
+  *cap = 0;
+  const size_t take = need + need / 4;
+  const hipError_t e = hipMalloc((void**)buf, take * sizeof(T));
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(e == hipErrorOutOfMemory ? RT_ERR_NOMEM : RT_ERR_DEVICE, "cannot allocate a work buffer");
+  }
+  *cap = take;
+  return RT_OK;
+}
+
+// GraphicalUI::applyFilter + the walk of doAntiAliasing over its mask
+// (src/ui/GraphicalUI.cpp:437-486,405-425) for a base image in device memory:
+// the (x, y) list of the flagged pixels, row by row, in RtScene::flagList.
+// Mask, counts and list stay on the device, in buffers the handle keeps; the
+// host learns one number -- how many pixels were flagged -- through mapped host
+// memory, because the second pass is sized by it.
+int buildFlagList(RtScene* sc, const unsigned char* rgbDev, int w, int h, int cutoff) {
+  const long long npx = (long long)w * h;
+  const int nBlocks = gridFor(npx);
+  sc->flagCount = 0;
+  int rc = growBuffer(&sc->flagMask, &sc->flagMaskCap, (size_t)npx);
+  if (rc != RT_OK) return rc;
+  rc = growBuffer(&sc->flagRuns, &sc->flagRunsCap, (size_t)nBlocks);
+  if (rc != RT_OK) return rc;
+  unsigned int* totalHost = reinterpret_cast<unsigned int*>(sc->countersHost);   // pinned, device-visible
+  *totalHost = 0;
+  k_edge_mask<<<nBlocks, kBlock, 0, sc->stream>>>(rgbDev, w, h, cutoff, sc->flagMask);
+  k_flag_count<<<nBlocks, kBlock, 0, sc->stream>>>(sc->flagMask, npx, sc->flagRuns);
+  k_flag_scan<<<1, 1024, 0, sc->stream>>>(sc->flagRuns, nBlocks, totalHost);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(sc->stream));
+  const long long nFlag = (long long)*totalHost;
+  if (nFlag > 0) {
+    rc = growBuffer(&sc->flagList, &sc->flagListCap, (size_t)nFlag * 2);
+    if (rc != RT_OK) return rc;
+    k_flag_write<<<nBlocks, kBlock, 0, sc->stream>>>(sc->flagMask, w, npx, sc->flagRuns, sc->flagList);
+    HIP_TRY(hipGetLastError());
+  }
+  sc->flagCount = nFlag;
+  sc->flagW = w;
+  sc->flagH = h;
   return RT_OK;
 }
 
@@ -2580,6 +2657,8 @@ int rt_render(RtScene* sc, const RtRenderParams* rp, unsigned char* rgb8_out, in
   fm.shardIndex = rp->shard_index; fm.shardCount = rp->shard_count;
   fm.pixelList = nullptr;
   fm.listOutput = 0;
+  fm.listFirst = 0;
+  fm.listStride = 1;
   fm.ns = (rp->aa_mode == RT_AA_FULL) ? nsFull : 1;
   fm.aaN = (rp->aa_mode == RT_AA_FULL) ? rp->aa_samples : 0;
   fm.jitter = (rp->aa_mode != RT_AA_NONE && rp->jitter) ? sc->jitterDev : nullptr;
@@ -2596,32 +2675,16 @@ int rt_render(RtScene* sc, const RtRenderParams* rp, unsigned char* rgb8_out, in
   if (rc != RT_OK) return rc;
   cx.stats.rays_primary = (unsigned long long)TL.pixels * fm.ns;
 
-  DevBuf maskBuf, countBuf, listBuf;
   if (rp->aa_mode == RT_AA_ADAPTIVE) {
     // GraphicalUI::doAntiAliasing (ui/GraphicalUI.cpp:377-435): edge mask on the
     // finished base image, then tracePixelAntiAlias on the flagged pixels only.
-    // Mask, count and list stay on the device; the host learns one number, how
-    // many pixels were flagged (through mapped host memory, no copy), because
-    // the second pass is sized by it.
-    const long long npx = (long long)w * h;
-    const int nBlocks = gridFor(npx);
-    HIP_TRY(maskBuf.alloc((size_t)npx));
-    HIP_TRY(countBuf.alloc((size_t)nBlocks * sizeof(unsigned int)));
-    unsigned char* maskDev = maskBuf.as<unsigned char>();
-    unsigned int* countDev = countBuf.as<unsigned int>();
-    unsigned int* totalHost = reinterpret_cast<unsigned int*>(sc->countersHost);   // pinned, device-visible
-    *totalHost = 0;
-    k_edge_mask<<<nBlocks, kBlock, 0, sc->stream>>>(sc->frameRgb, w, h, rp->aa_threshold, maskDev);
-    k_flag_count<<<nBlocks, kBlock, 0, sc->stream>>>(maskDev, npx, countDev);
-    k_flag_scan<<<1, 1024, 0, sc->stream>>>(countDev, nBlocks, totalHost);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(sc->stream));
-    const long long nFlag = (long long)*totalHost;
+    rc = buildFlagList(sc, sc->frameRgb, w, h, rp->aa_threshold);
+    if (rc != RT_OK) return rc;
+    const long long nFlag = sc->flagCount;
     if (nFlag > 0) {
-      HIP_TRY(listBuf.alloc((size_t)nFlag * 2 * sizeof(int)));
-      int* listDev = listBuf.as<int>();
-      k_flag_write<<<nBlocks, kBlock, 0, sc->stream>>>(maskDev, w, npx, countDev, listDev);
-      fm.pixelList = listDev;
+      fm.pixelList = sc->flagList;
+      fm.listFirst = 0;
+      fm.listStride = 1;
       fm.ns = nsFull;
       fm.aaN = rp->aa_samples;
       setDivisors(fm);
@@ -2630,10 +2693,7 @@ int rt_render(RtScene* sc, const RtRenderParams* rp, unsigned char* rgb8_out, in
       rc = renderRange(cx, 0, nFlag);
       cx.hitDev = keepHit;
       cx.stats.rays_primary += (unsigned long long)nFlag * nsFull;
-      if (rc != RT_OK) {
-        hipStreamSynchronize(sc->stream);   // the buffers go away with this call
-        return rc;
-      }
+      if (rc != RT_OK) return rc;
     }
   }
   HIP_TRY(hipEventRecord(sc->evStop, sc->stream));
@@ -2685,39 +2745,25 @@ int rt_render(RtScene* sc, const RtRenderParams* rp, unsigned char* rgb8_out, in
   return RT_OK;
 }
 
-int rt_render_pixels(RtScene* sc, const RtRenderParams* rp, int n_pixels, const int* xy, unsigned char* rgb8_out,
-                     RtStats* stats_out) {
-  if (!sc || !rp || n_pixels < 0 || (n_pixels > 0 && (!xy || !rgb8_out))) return fail(RT_ERR_INVALID, "null argument");
-  if (rp->width <= 0 || rp->height <= 0 || rp->depth < 0) return fail(RT_ERR_INVALID, "bad frame size or depth");
-  if (rp->depth > kMaxDepth) return fail(RT_ERR_UNSUPPORTED, "recursion depth above 126");
-  if (rp->aa_mode != RT_AA_NONE && (rp->aa_samples < 1 || rp->aa_samples > 8))
-    return fail(RT_ERR_INVALID, "aa_samples must be 1..8");
-  if (rp->traversal != RT_TRAVERSE_REFERENCE && rp->traversal != RT_TRAVERSE_FAST)
-    return fail(RT_ERR_INVALID, "bad traversal mode");
-  for (int k = 0; k < n_pixels; k++)
-    if (xy[2 * k] < 0 || xy[2 * k] >= rp->width || xy[2 * k + 1] < 0 || xy[2 * k + 1] >= rp->height)
-      return fail(RT_ERR_INVALID, "listed pixel outside the frame");
+}  // extern "C"
+
+namespace {
+
+// tracePixel / tracePixelAntiAlias on entries first, first + stride, ... (count
+// of them) of an (x, y) list in device memory; 3 bytes per entry, in that
+// order, to outDev.  Queued on the scene's stream and waited for.
+int renderListed(RtScene* sc, const RtRenderParams* rp, const int* listDev, long long first, long long stride,
+                 long long count, unsigned char* outDev, RtStats* stats_out) {
   const auto t0 = std::chrono::steady_clock::now();
-  HIP_TRY(hipSetDevice(sc->device));
   RenderCtx cx;
   cx.sc = sc;
   cx.rp = rp;
   std::memset(&cx.stats, 0, sizeof cx.stats);
-  if (n_pixels == 0) {
-    if (stats_out) *stats_out = cx.stats;
-    return RT_OK;
-  }
   const int ns = (rp->aa_mode == RT_AA_NONE) ? 1 : rp->aa_samples * rp->aa_samples;
-  int rc = sizePool(sc, rp, (long long)n_pixels * ns);
+  int rc = sizePool(sc, rp, count * ns);
   if (rc != RT_OK) return rc;
   rc = uploadJitter(sc, rp, ns);
   if (rc != RT_OK) return rc;
-  DevBuf listBuf, outBuf;
-  HIP_TRY(listBuf.alloc((size_t)n_pixels * 2 * sizeof(int)));
-  if (outBuf.alloc((size_t)n_pixels * 3) != hipSuccess) return fail(RT_ERR_NOMEM, "cannot allocate the pixel list output");
-  int* listDev = listBuf.as<int>();
-  unsigned char* outDev = outBuf.as<unsigned char>();
-  HIP_TRY(hipMemcpyAsync(listDev, xy, (size_t)n_pixels * 2 * sizeof(int), hipMemcpyHostToDevice, sc->stream));
   cx.fast = rp->traversal == RT_TRAVERSE_FAST;
   cx.wantStats = rp->collect_stats != 0;
   cx.rgbDev = outDev;
@@ -2726,9 +2772,12 @@ int rt_render_pixels(RtScene* sc, const RtRenderParams* rp, int n_pixels, const 
   FrameMap& fm = cx.fm;
   fm.width = rp->width; fm.height = rp->height;
   fm.tileW = fm.tileH = 8; fm.tilesX = 1;
-  fm.shardIndex = 0; fm.shardCount = 1;
+  // (the share of the list stands where the shard of a tiled frame stands: it is part of what a batch is)
+  fm.shardIndex = (int)first; fm.shardCount = (int)stride;
   fm.pixelList = listDev;
   fm.listOutput = 1;
+  fm.listFirst = (int)first;
+  fm.listStride = (int)stride;
   fm.ns = ns;
   fm.aaN = (rp->aa_mode == RT_AA_NONE) ? 0 : rp->aa_samples;
   fm.jitter = (rp->aa_mode != RT_AA_NONE && rp->jitter) ? sc->jitterDev : nullptr;
@@ -2737,16 +2786,15 @@ int rt_render_pixels(RtScene* sc, const RtRenderParams* rp, int n_pixels, const 
   if (rc != RT_OK) return rc;
   sc->eventsUsed = 0;
   HIP_TRY(hipEventRecord(sc->evStart, sc->stream));
-  rc = renderRange(cx, 0, n_pixels);
+  rc = renderRange(cx, 0, count);
   if (rc != RT_OK) {
-    hipStreamSynchronize(sc->stream);   // the buffers go away with this call
+    hipStreamSynchronize(sc->stream);
     return rc;
   }
   HIP_TRY(hipEventRecord(sc->evStop, sc->stream));
-  HIP_TRY(hipMemcpyAsync(rgb8_out, outDev, (size_t)n_pixels * 3, hipMemcpyDeviceToHost, sc->stream));
   HIP_TRY(hipStreamSynchronize(sc->stream));
   if (cx.usedSamples > 0.0) sc->growth = 1.1 * cx.usedSlots / cx.usedSamples + 0.05;
-  cx.stats.rays_primary = (unsigned long long)n_pixels * ns;
+  cx.stats.rays_primary = (unsigned long long)count * ns;
   float ms = 0.f;
   if (hipEventElapsedTime(&ms, sc->evStart, sc->evStop) == hipSuccess) cx.stats.ms_device = ms;
   for (size_t e = 0; e + 1 < sc->eventsUsed; e += 2) {
@@ -2757,6 +2805,88 @@ int rt_render_pixels(RtScene* sc, const RtRenderParams* rp, int n_pixels, const 
   cx.stats.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   if (stats_out) *stats_out = cx.stats;
   return RT_OK;
+}
+
+int checkListedParams(const RtRenderParams* rp) {
+  if (rp->width <= 0 || rp->height <= 0 || rp->depth < 0) return fail(RT_ERR_INVALID, "bad frame size or depth");
+  if (rp->depth > kMaxDepth) return fail(RT_ERR_UNSUPPORTED, "recursion depth above 126");
+  if (rp->aa_mode != RT_AA_NONE && (rp->aa_samples < 1 || rp->aa_samples > 8))
+    return fail(RT_ERR_INVALID, "aa_samples must be 1..8");
+  if (rp->traversal != RT_TRAVERSE_REFERENCE && rp->traversal != RT_TRAVERSE_FAST)
+    return fail(RT_ERR_INVALID, "bad traversal mode");
+  return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rt_render_pixels(RtScene* sc, const RtRenderParams* rp, int n_pixels, const int* xy, unsigned char* rgb8_out,
+                     RtStats* stats_out) {
+  if (!sc || !rp || n_pixels < 0 || (n_pixels > 0 && (!xy || !rgb8_out))) return fail(RT_ERR_INVALID, "null argument");
+  int rc = checkListedParams(rp);
+  if (rc != RT_OK) return rc;
+  for (int k = 0; k < n_pixels; k++)
+    if (xy[2 * k] < 0 || xy[2 * k] >= rp->width || xy[2 * k + 1] < 0 || xy[2 * k + 1] >= rp->height)
+      return fail(RT_ERR_INVALID, "listed pixel outside the frame");
+  HIP_TRY(hipSetDevice(sc->device));
+  if (n_pixels == 0) {
+    if (stats_out) std::memset(stats_out, 0, sizeof *stats_out);
+    return RT_OK;
+  }
+  // the caller's list and the colours of its pixels, staged in a buffer the handle keeps
+  const size_t listBytes = (size_t)n_pixels * 2 * sizeof(int);
+  rc = growBuffer(&sc->listStage, &sc->listStageCap, listBytes + (size_t)n_pixels * 3);
+  if (rc != RT_OK) return rc;
+  int* listDev = reinterpret_cast<int*>(sc->listStage);
+  unsigned char* outDev = sc->listStage + listBytes;
+  HIP_TRY(hipMemcpyAsync(listDev, xy, listBytes, hipMemcpyHostToDevice, sc->stream));
+  rc = renderListed(sc, rp, listDev, 0, 1, n_pixels, outDev, stats_out);
+  if (rc != RT_OK) return rc;
+  HIP_TRY(hipMemcpyAsync(rgb8_out, outDev, (size_t)n_pixels * 3, hipMemcpyDeviceToHost, sc->stream));
+  HIP_TRY(hipStreamSynchronize(sc->stream));
+  return RT_OK;
+}
+
+int rt_render_flagged(RtScene* sc, const RtRenderParams* rp, const unsigned char* base_rgb_dev, int share_index,
+                      int share_count, unsigned char* rows_dev, long long rows_capacity, long long* n_flagged,
+                      long long* n_rendered, RtStats* stats_out) {
+  if (!sc || !rp || !base_rgb_dev) return fail(RT_ERR_INVALID, "null argument");
+  if (share_count <= 0 || share_index < 0 || share_index >= share_count) return fail(RT_ERR_INVALID, "bad share index/count");
+  int rc = checkListedParams(rp);
+  if (rc != RT_OK) return rc;
+  if (rp->aa_mode == RT_AA_NONE) return fail(RT_ERR_INVALID, "the second pass of adaptive anti-aliasing needs aa_samples");
+  HIP_TRY(hipSetDevice(sc->device));
+  rc = buildFlagList(sc, base_rgb_dev, rp->width, rp->height, rp->aa_threshold);
+  if (rc != RT_OK) return rc;
+  const long long total = sc->flagCount;
+  const long long mine = total > share_index ? (total - share_index + share_count - 1) / share_count : 0;
+  if (n_flagged) *n_flagged = total;
+  if (n_rendered) *n_rendered = mine;
+  if (stats_out) std::memset(stats_out, 0, sizeof *stats_out);
+  if (mine == 0) {
+    HIP_TRY(hipStreamSynchronize(sc->stream));
+    return RT_OK;
+  }
+  if (!rows_dev || rows_capacity < mine) return fail(RT_ERR_INVALID, "rows buffer smaller than this share of the flagged pixels");
+  RtRenderParams p = *rp;
+  p.aa_mode = RT_AA_FULL;
+  return renderListed(sc, &p, sc->flagList, share_index, share_count, mine, rows_dev, stats_out);
+}
+
+int rt_patch_flagged(RtScene* sc, int share_index, int share_count, const unsigned char* rows_dev,
+                     unsigned char* frame_dev, void* hip_stream) {
+  if (!sc || !frame_dev) return fail(RT_ERR_INVALID, "null argument");
+  if (share_count <= 0 || share_index < 0 || share_index >= share_count) return fail(RT_ERR_INVALID, "bad share index/count");
+  const long long total = sc->flagCount;
+  const long long n = total > share_index ? (total - share_index + share_count - 1) / share_count : 0;
+  if (n == 0) return RT_OK;
+  if (!rows_dev) return fail(RT_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(sc->device));
+  k_patch_listed<<<gridFor(n), kBlock, 0, (hipStream_t)hip_stream>>>(sc->flagList, share_index, share_count, n, rows_dev,
+                                                                      sc->flagW, frame_dev);
+  HIP_TRY(hipGetLastError());
+  return RT_OK;   // stream-ordered: the caller synchronises hip_stream
 }
 
 int rt_intersect_batch(RtScene* sc, int traversal, int n, const double* rays_pd, const int* ray_types,

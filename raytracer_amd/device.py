@@ -113,6 +113,19 @@ class DeviceScene:
                                       C.byref(st)), "rt_render_pixels")
         return out, st
 
+    def render_flagged(self, params, base_dev_ptr, share_index, share_count, rows_dev_ptr, rows_capacity):
+        """Second pass of adaptive anti-aliasing for one share of the flagged pixels of a base image that is
+        complete in this device's memory; returns (pixels flagged in the frame, pixels of this share, RtStats)."""
+        total, mine, st = C.c_longlong(0), C.c_longlong(0), abi.RtStats()
+        _check(lib().rt_render_flagged(self._h, C.byref(params), C.c_void_p(base_dev_ptr), share_index, share_count,
+                                       C.c_void_p(rows_dev_ptr), rows_capacity, C.byref(total), C.byref(mine),
+                                       C.byref(st)), "rt_render_flagged")
+        return total.value, mine.value, st
+
+    def patch_flagged(self, share_index, share_count, rows_dev_ptr, frame_dev_ptr, stream=0):
+        _check(lib().rt_patch_flagged(self._h, share_index, share_count, C.c_void_p(rows_dev_ptr),
+                                      C.c_void_p(frame_dev_ptr), C.c_void_p(stream)), "rt_patch_flagged")
+
     def intersect(self, rays_pd, types=None, traversal=abi.RT_TRAVERSE_REFERENCE):
         rays = np.ascontiguousarray(rays_pd, dtype=np.float64).reshape(-1, 6)
         n = len(rays)

@@ -117,7 +117,14 @@ def render_adaptive(ds, width, height, render_kw, aa_samples, aa_threshold, jitt
                     tile=32, device="cuda"):
     """Adaptive anti-aliasing of one frame over world_size ranks (this is rank
     `rank`; ds is its DeviceScene).  Returns the finished (H, W, 3) uint8 frame
-    on rank 0 (numpy, row 0 = bottom row), None elsewhere."""
+    on rank 0 (numpy, row 0 = bottom row), None elsewhere.
+
+    The frame never leaves the devices between the two passes: the base image
+    is completed on every rank by one all-gather, every rank builds the same
+    edge mask and flagged-pixel list on its device (rt_render_flagged) and
+    re-renders every world_size-th entry, one gather brings the re-rendered
+    pixels to rank 0, which writes them over the base image on its device
+    (rt_patch_flagged)."""
     import torch
     import torch.distributed as dist
     from . import abi, device as dev, host
@@ -136,23 +143,23 @@ def render_adaptive(ds, width, height, render_kw, aa_samples, aa_threshold, jitt
     else:
         shards = [packed]
     frame_dev = torch.zeros((height, width, 3), dtype=torch.uint8, device=device)
+    stream = torch.cuda.current_stream().cuda_stream
     for r, b in enumerate(shards):
-        dev.unpack_tiles(b.data_ptr(), 3, width, height, tile, tile, r, world_size, frame_dev.data_ptr(),
-                         torch.cuda.current_stream().cuda_stream)
-    torch.cuda.synchronize()
-    base = frame_dev.cpu().numpy()
+        dev.unpack_tiles(b.data_ptr(), 3, width, height, tile, tile, r, world_size, frame_dev.data_ptr(), stream)
+    torch.cuda.current_stream().synchronize()   # the library reads the frame on its own stream
 
     # pass 2: this rank's share of the flagged pixels with n x n samples
-    xy = flagged_pixels(dev.edge_mask(base, aa_threshold))
-    mine = flagged_share(xy, rank, world_size)
-    pa, keep = host.render_params(width, height, aa_mode=abi.RT_AA_FULL, aa_samples=aa_samples, jitter=jitter,
-                                  **render_kw)
-    rgb, _ = ds.render_pixels(pa, mine)
-    most = (len(xy) + world_size - 1) // world_size
-    rows = gather_rows(torch.from_numpy(rgb).to(device), max(most, 1), world_size, rank)
+    cap = (width * height + world_size - 1) // world_size
+    rows = torch.zeros((cap, 3), dtype=torch.uint8, device=device)
+    torch.cuda.current_stream().synchronize()
+    pa, keep = host.render_params(width, height, aa_mode=abi.RT_AA_FULL, aa_samples=aa_samples,
+                                  aa_threshold=aa_threshold, jitter=jitter, **render_kw)
+    total, mine, _ = ds.render_flagged(pa, frame_dev.data_ptr(), rank, world_size, rows.data_ptr(), cap)
+    most = max((total + world_size - 1) // world_size, 1)        # the same on every rank
+    gathered = gather_rows(rows[:mine], most, world_size, rank)
     if rank != 0:
         return None
-    for r, b in enumerate(rows):
-        share = flagged_share(xy, r, world_size)
-        patch_pixels(base, share, b[:len(share)].cpu().numpy())
-    return base
+    for r, b in enumerate(gathered):
+        ds.patch_flagged(r, world_size, b.data_ptr(), frame_dev.data_ptr(), stream)
+    torch.cuda.current_stream().synchronize()
+    return frame_dev.cpu().numpy()

@@ -325,6 +325,27 @@ def test_adaptive_antialiasing_over_shards(built):
     # the one-rank form of the distributed driver takes the same path
     whole = parallel.render_adaptive(ds, w, h, kw, 3, 40, jit, 1, 0)
     assert np.array_equal(whole, single)
+    # the device-resident second pass share by share, as three ranks would run it: the base image stays
+    # in device memory, every share is rendered from the list built there and patched in there
+    import torch
+    frame_dev = torch.from_numpy(base).cuda()
+    cap = (w * h + world - 1) // world
+    rows = [torch.zeros((cap, 3), dtype=torch.uint8, device="cuda") for _ in range(world)]
+    torch.cuda.synchronize()
+    pf, keep2 = host.render_params(w, h, aa_mode=abi.RT_AA_FULL, aa_samples=3, aa_threshold=40, jitter=jit, **kw)
+    seen = 0
+    for r in range(world):
+        total, mine, st = ds.render_flagged(pf, frame_dev.data_ptr(), r, world, rows[r].data_ptr(), cap)
+        assert total == len(xy) and mine == len(parallel.flagged_share(xy, r, world))
+        assert st.rays_primary == 9 * mine
+        seen += mine
+    assert seen == len(xy)
+    for r in range(world):
+        ds.patch_flagged(r, world, rows[r].data_ptr(), frame_dev.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(frame_dev.cpu().numpy(), single)
+    with pytest.raises(device.DeviceError, match="smaller"):
+        ds.render_flagged(pf, frame_dev.data_ptr(), 0, 1, rows[0].data_ptr(), 3)
     # an empty list is fine
     rgb, st = ds.render_pixels(pa, np.zeros((0, 2), dtype=np.int32))
     assert len(rgb) == 0 and st.rays_total == 0
