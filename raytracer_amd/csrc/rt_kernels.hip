@@ -632,8 +632,8 @@ k_background(DevScene S, RaySrc R, int filterWidth, long long traced, Pool P) {
 // and the traversal may stop at any occluder in front of the light, just
 // whether there is one (`anyOccluder`).
 template <bool FAST, bool STATS, bool TRI>
-__device__ __forceinline__ void shadowQuery(const DevScene& S, const RtLight& l, const V3& Q, int& prim, double& th,
-                                            bool& anyOccluder, TraceCounters& tc) {
+__device__ __forceinline__ void shadowQuery(const DevScene& S, const RtLight& l, const double* cone, const V3& Q, int& prim,
+                                            double& th, bool& anyOccluder, TraceCounters& tc) {
   anyOccluder = false;
   if (l.type == RT_LIGHT_DIRECTIONAL) {
     const V3 sd = normalized(-V3(l.orientation));
@@ -644,6 +644,21 @@ __device__ __forceinline__ void shadowQuery(const DevScene& S, const RtLight& l,
   }
   const V3 position(l.position);
   const V3 sd = normalized(position - Q);
+  if (FAST && l.type == RT_LIGHT_SPOT) {
+    // A point outside the cone gets (0, 0, 0) from SpotLight::shadowAttenuation
+    // whether its shadow ray hits something or not (light.cpp:127-133 and
+    // 141-145 test the same angle on both sides of the occlusion test): the
+    // query's outcome cannot reach the colour, so it is not run.  (The ray
+    // still counts as cast: shadow rays are counted as lit points x lights.)
+    // The same decision as lightIntensityFrom's, taken only where it needs no
+    // acos; in the hair around the cone's edge the query runs.
+    const double x = dot(V3(l.orientation), sd * -1);
+    if (x < cone[0] && x >= -1.0) {
+      prim = RT_PRIM_NONE;
+      th = 0.0;
+      return;
+    }
+  }
   const double lightDistance = length2(position - Q);
   // FAST: an occluder beyond the light is irrelevant; bound the search a little
   // past the light so that the strict < of the caller decides
@@ -742,7 +757,7 @@ k_shadow(DevScene S, Pool P) {
       double th;
       bool anyOccluder;
       const RtLight& l = S.lights[li];
-      shadowQuery<FAST, STATS, TRI>(S, l, Q, prim, th, anyOccluder, tc);
+      shadowQuery<FAST, STATS, TRI>(S, l, S.spotCone + 4 * li, Q, prim, th, anyOccluder, tc);
       if (!P.shT && !anyOccluder && prim != RT_PRIM_NONE && l.type != RT_LIGHT_DIRECTIONAL) {
         // The pool of an opaque scene keeps no hit parameter, so the closest
         // occluder is held against the light here, with the expressions of
