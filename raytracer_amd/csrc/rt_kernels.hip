@@ -2412,7 +2412,81 @@ int rt_scene_create(const RtSceneDesc* d, RtScene** out) {
         // (only the kernels of triangle-only scenes read this form: 1 KiB per
         // node, sixteen times the quantised node array)
         // the same child boxes decoded to binary32 planes, outward rounded
-        static_assert(sizeof(DevBvhNodeF) == 128, "float BVH node must be 128 bytes");
+        static_assert(sizeof(DevBvhNodeF) == RT_BVHF_BYTES, "float BVH node size");
+        // Normal cone of every child of every node (see DevBvhNodeF::cone).  The
+        // binary builder partitions the triangle array in place, so the
+        // triangles below a child are a contiguous run of the leaf-ordered
+        // array: axis = the normalised sum of the run's unit normals, opening =
+        // the widest angle any of them makes with it.
+        struct Run { int lo, hi; };
+        std::vector<std::array<float, 16>> cones(wide.nodes.size());
+        {
+          std::vector<std::array<double, 3>> unit(ordered.size());
+          std::vector<char> valid(ordered.size(), 0);
+          for (size_t t = 0; t < ordered.size(); t++) {
+            const double* nn = ordered[t].n;
+            const double len = std::sqrt(nn[0] * nn[0] + nn[1] * nn[1] + nn[2] * nn[2]);
+            // a triangle without a direction (null or NaN normal) is never hit, whatever the ray
+            if (len > 0.0 && std::isfinite(len)) {
+              unit[t] = {nn[0] / len, nn[1] / len, nn[2] / len};
+              valid[t] = 1;
+            }
+          }
+          auto coneOf = [&](Run r, float* out) {
+            double ax[3] = {0.0, 0.0, 0.0};
+            for (int t = r.lo; t < r.hi; t++)
+              if (valid[(size_t)t]) for (int a = 0; a < 3; a++) ax[a] += unit[(size_t)t][a];
+            const double al = std::sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
+            out[0] = out[1] = out[2] = 0.0f;
+            out[3] = 2.0f;
+            if (!(al > 1e-9)) return;
+            for (int a = 0; a < 3; a++) { ax[a] /= al; out[a] = (float)ax[a]; }
+            double cosMin = 1.0;
+            for (int t = r.lo; t < r.hi; t++)
+              if (valid[(size_t)t])
+                cosMin = std::min(cosMin, (double)out[0] * unit[(size_t)t][0] + (double)out[1] * unit[(size_t)t][1] +
+                                              (double)out[2] * unit[(size_t)t][2]);
+            if (cosMin <= 0.05) return;   // wider than 87 degrees: nothing to gain
+            // sin(theta), and room for the binary32 roundings of axis, direction and dot product
+            const double sinMax = std::sqrt(std::max(0.0, 1.0 - cosMin * cosMin));
+            out[3] = (float)(sinMax * (1.0 + 1.0e-4) + 1.0e-5);
+            if (out[3] >= 1.0f) out[3] = 2.0f;
+          };
+          // runs bottom-up: the children of a node come after it in `wide.nodes` (the collapser appends them).
+          // An empty run marks a child without triangles of its own (an unused slot, which points at the
+          // null triangle at the end of the array; a non-mesh object).
+          const int nullTriangle = (int)ordered.size() - 1;
+          std::vector<std::array<Run, 4>> runs(wide.nodes.size());
+          std::vector<Run> whole(wide.nodes.size());
+          for (size_t i = wide.nodes.size(); i-- > 0;) {
+            Run all{INT32_MAX, -1};
+            for (int c = 0; c < 4; c++) {
+              const int32_t ref = wide.nodes[i].child[c];
+              Run r{0, -1};
+              if (ref >= 0) {
+                r = whole[(size_t)ref];
+              } else {
+                const int x = ~ref;
+                if (!(x & rtbvh::kObjectBit) && (x >> 3) != nullTriangle) r = Run{x >> 3, (x >> 3) + (x & 7) + 1};
+              }
+              runs[i][(size_t)c] = r;
+              if (r.hi > r.lo) { all.lo = std::min(all.lo, r.lo); all.hi = std::max(all.hi, r.hi); }
+            }
+            whole[i] = all;
+          }
+          bool any = false;
+          for (size_t i = 0; i < wide.nodes.size(); i++)
+            for (int c = 0; c < 4; c++) {
+              float* out = &cones[i][(size_t)(4 * c)];
+              out[0] = out[1] = out[2] = 0.0f;
+              out[3] = 2.0f;
+              const Run r = runs[i][(size_t)c];
+              if (r.hi > r.lo && sc->triOnly) coneOf(r, out);
+              any = any || out[3] < 1.0f;
+            }
+          D.bvhCones = any ? 1 : 0;
+          if (const char* e = std::getenv("RT_AMD_CONES")) { if (std::atoi(e) == 0) D.bvhCones = 0; }
+        }
         // Eight copies per node, copy o for rays whose direction is negative on
         // the axes of o's set bits, its children sorted near to far along that
         // diagonal (box centres; unused slots, whose boxes are inverted, last).
@@ -2447,6 +2521,7 @@ int rt_scene_create(const RtSceneDesc* d, RtScene** out) {
               const int c = order[j];
               F.child[j] = n4.child[c];
               for (int a = 0; a < 3; a++) { lo[a][j] = blo[a][c]; hi[a][j] = bhi[a][c]; }
+              for (int a = 0; a < 4; a++) F.cone[j][a] = cones[i][(size_t)(4 * c + a)];
             }
           }
         }

@@ -80,7 +80,16 @@ struct DevBvhNodeF {
   float lo_x[4], hi_x[4], lo_y[4], hi_y[4], lo_z[4], hi_z[4];
   int child[4];
   int pad[4];
+  // Normal cone of each child: every triangle below child c has a face normal n
+  // with cone[c][0..2] . n / |n| >= cos(theta_c), and cone[c][3] bounds
+  // sin(theta_c) from above (2: no bound, or a child that holds something other
+  // than triangles).  A ray with unit direction d and cone . d > cone[c][3]
+  // meets every such triangle from behind: where back faces are culled
+  // (TrimeshFace::intersectLocal, trimesh.cpp:93-104: normal . d > 0 -> miss)
+  // nothing below the child can be hit and the child is not entered.
+  float cone[4][4];
 };
+#define RT_BVHF_BYTES 192
 
 // What the shading kernels need of one (non-interpolated) material, derived
 // once at scene creation with the reference's own expressions.
@@ -143,6 +152,7 @@ struct DevScene {
   // (what a slab distance's rounding error grows with, see bvhRaySetup)
   float bvhErrG[3];
   int bvhLaneF;              // 1: bvhF is small enough for 32-bit byte offsets (bvhNodeSlabsLane)
+  int bvhCones;              // 1: the normal cones of bvhF are worth testing (some child of some node can be culled by one)
   int bvh_valid;             // 0: empty scene
   int opaque;                // 1: no material transmits (kt == 0 everywhere)
 };
@@ -771,6 +781,10 @@ struct BvhRay {
   bool negx, negy, negz;  // direction sign per axis (false on a degenerate axis)
   bool zx, zy, zz;        // |d| < 1e-30 on that axis: inside / outside test instead of a slab
   bool cullBack;
+  // the direction in binary32 where back faces are culled for this ray and the
+  // tree carries normal cones (DevBvhNodeF::cone), else (0, 0, 0): no cone test
+  // can then come out above its positive threshold
+  float dfx, dfy, dfz;
 };
 
 __device__ __forceinline__ void bvhRaySetup(const DevScene& S, const V3& p, const V3& d, int rayType, BvhRay& r) {
@@ -805,6 +819,11 @@ __device__ __forceinline__ void bvhRaySetup(const DevScene& S, const V3& p, cons
   r.negx = (d.x < 0.0) & !r.zx;
   r.negy = (d.y < 0.0) & !r.zy;
   r.negz = (d.z < 0.0) & !r.zz;
+  // (every ray of the render path has a unit direction; the cones' thresholds leave room for its rounding)
+  const bool cones = r.cullBack && S.bvhCones;
+  r.dfx = cones ? (float)d.x : 0.0f;
+  r.dfy = cones ? (float)d.y : 0.0f;
+  r.dfz = cones ? (float)d.z : 0.0f;
 }
 
 // The rest of the setup, for rays that get past the root box: what the
@@ -917,10 +936,15 @@ typedef int rt_i4 __attribute__((ext_vector_type(4)));
 // RAW: tn[c] is the entry distance whether the child is hit or not and hit[c]
 // says which it is (what the ordered descent of a closest-hit query wants);
 // otherwise tn[c] is +inf for a child that is not hit and hit[] is not written.
+typedef float rt_f8 __attribute__((ext_vector_type(8)));
+
+// CONES (with RAW): children whose normal cone says that the ray meets every
+// triangle below them from behind are struck from the hit masks (see
+// DevBvhNodeF::cone); wave-uniform switch `cones`.
 template <bool RAW>
 __device__ __forceinline__ void bvhNodeSlabsUniform(const DevScene& S, const BvhRay& r, int ref, unsigned int negMask,
                                                     unsigned int copy, float bestTf, float tn[4], int kid[4],
-                                                    rt_mask hit[4]) {
+                                                    rt_mask hit[4], bool cones = false) {
   const float kInf = __int_as_float(0x7f800000);
   // eight copies of every node, one per combination of direction signs, each
   // with its children listed near to far for directions of those signs
@@ -930,18 +954,37 @@ __device__ __forceinline__ void bvhNodeSlabsUniform(const DevScene& S, const Bvh
   const unsigned int oFX = oNX ^ 16u, oFY = oNY ^ 16u, oFZ = oNZ ^ 16u;
   rt_f4 nX, fX, nY, fY, nZ, fZ;
   rt_i4 kids;
-  asm volatile(
-      "s_load_dwordx4 %0, %7, %8\n\t"
-      "s_load_dwordx4 %1, %7, %9\n\t"
-      "s_load_dwordx4 %2, %7, %10\n\t"
-      "s_load_dwordx4 %3, %7, %11\n\t"
-      "s_load_dwordx4 %4, %7, %12\n\t"
-      "s_load_dwordx4 %5, %7, %13\n\t"
-      "s_load_dwordx4 %6, %7, 0x60\n\t"
-      "s_waitcnt lgkmcnt(0)"
-      : "=&s"(nX), "=&s"(fX), "=&s"(nY), "=&s"(fY), "=&s"(nZ), "=&s"(fZ), "=&s"(kids)
-      : "s"(np), "s"(oNX), "s"(oFX), "s"(oNY), "s"(oFY), "s"(oNZ), "s"(oFZ)
-      : "memory");
+  rt_f8 cone01, cone23;
+  if (RAW && cones) {
+    // (one statement, so that nothing that reads a result can come before the wait)
+    asm volatile(
+        "s_load_dwordx4 %0, %9, %10\n\t"
+        "s_load_dwordx4 %1, %9, %11\n\t"
+        "s_load_dwordx4 %2, %9, %12\n\t"
+        "s_load_dwordx4 %3, %9, %13\n\t"
+        "s_load_dwordx4 %4, %9, %14\n\t"
+        "s_load_dwordx4 %5, %9, %15\n\t"
+        "s_load_dwordx4 %6, %9, 0x60\n\t"
+        "s_load_dwordx8 %7, %9, 0x80\n\t"
+        "s_load_dwordx8 %8, %9, 0xa0\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&s"(nX), "=&s"(fX), "=&s"(nY), "=&s"(fY), "=&s"(nZ), "=&s"(fZ), "=&s"(kids), "=&s"(cone01), "=&s"(cone23)
+        : "s"(np), "s"(oNX), "s"(oFX), "s"(oNY), "s"(oFY), "s"(oNZ), "s"(oFZ)
+        : "memory");
+  } else {
+    asm volatile(
+        "s_load_dwordx4 %0, %7, %8\n\t"
+        "s_load_dwordx4 %1, %7, %9\n\t"
+        "s_load_dwordx4 %2, %7, %10\n\t"
+        "s_load_dwordx4 %3, %7, %11\n\t"
+        "s_load_dwordx4 %4, %7, %12\n\t"
+        "s_load_dwordx4 %5, %7, %13\n\t"
+        "s_load_dwordx4 %6, %7, 0x60\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&s"(nX), "=&s"(fX), "=&s"(nY), "=&s"(fY), "=&s"(nZ), "=&s"(fZ), "=&s"(kids)
+        : "s"(np), "s"(oNX), "s"(oFX), "s"(oNY), "s"(oFY), "s"(oNZ), "s"(oFZ)
+        : "memory");
+  }
   kid[0] = kids.x; kid[1] = kids.y; kid[2] = kids.z; kid[3] = kids.w;
   // Two children per packed multiply-add: planes from a scalar register pair,
   // the reciprocal and the offset picked out of register pairs of the ray's
@@ -978,6 +1021,16 @@ __device__ __forceinline__ void bvhNodeSlabsUniform(const DevScene& S, const Bvh
       tn[c + 1] = h1 ? tnear1 : kInf;
     }
   }
+  if (RAW && cones) {
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      if (hit[c] == 0) continue;   // nobody enters this child anyway (wave-uniform)
+      const float ax = c < 2 ? cone01[4 * c] : cone23[4 * c - 8], ay = c < 2 ? cone01[4 * c + 1] : cone23[4 * c - 7];
+      const float az = c < 2 ? cone01[4 * c + 2] : cone23[4 * c - 6], thr = c < 2 ? cone01[4 * c + 3] : cone23[4 * c - 5];
+      const float along = fmaf(az, r.dfz, fmaf(ay, r.dfy, ax * r.dfx));
+      hit[c] &= ~__ballot(along > thr);
+    }
+  }
 }
 
 // The same slab test for a lane that is at a node of its own: the planes of the
@@ -988,10 +1041,11 @@ __device__ __forceinline__ void bvhNodeSlabsUniform(const DevScene& S, const Bvh
 // arrive near to far.  No axis-parallel component (the caller checked).
 template <bool RAW>
 __device__ __forceinline__ void bvhNodeSlabsLane(const DevScene& S, const BvhRay& r, int ref, unsigned int copy,
-                                                 float bestTf, float tn[4], int kid[4], rt_mask hit[4]) {
+                                                 float bestTf, float tn[4], int kid[4], rt_mask hit[4],
+                                                 bool cones = false) {
   const float kInf = __int_as_float(0x7f800000);
   const char* base = reinterpret_cast<const char*>(S.bvhF);
-  const unsigned int node = ((unsigned int)ref * 8u + copy) * 128u;   // (node count checked at scene creation)
+  const unsigned int node = ((unsigned int)ref * 8u + copy) * (unsigned int)RT_BVHF_BYTES;   // (node count checked at scene creation)
   const unsigned int oNX = r.negx ? 16u : 0u, oNY = r.negy ? 48u : 32u, oNZ = r.negz ? 80u : 64u;
   const rt_f4 nX = *reinterpret_cast<const rt_f4*>(base + (node + oNX));
   const rt_f4 fX = *reinterpret_cast<const rt_f4*>(base + (node + (oNX ^ 16u)));
@@ -1032,6 +1086,15 @@ __device__ __forceinline__ void bvhNodeSlabsLane(const DevScene& S, const BvhRay
     }
   }
 #undef RT_PKFMA_V
+  if (RAW && cones) {   // see bvhNodeSlabsUniform
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      if (hit[c] == 0) continue;
+      const rt_f4 cn = *reinterpret_cast<const rt_f4*>(base + (node + 128u + 16u * c));
+      const float along = fmaf(cn.z, r.dfz, fmaf(cn.y, r.dfy, cn.x * r.dfx));
+      hit[c] &= ~__ballot(along > cn.w);
+    }
+  }
 }
 
 // (tn, kid) ascending by tn: network (0,1)(2,3)(0,2)(1,3)(1,2)
@@ -1281,6 +1344,8 @@ __device__ int traceBvh(const DevScene& S, const V3& p, const V3& d, int rayType
   const bool uniformOk = __ballot((myNeg != negMask) | r.zx | r.zy | r.zz) == 0;
   // this lane can read the binary32 planes by itself: no axis-parallel component, offsets fit 32 bits
   const bool laneOk = S.bvhLaneF && !(r.zx | r.zy | r.zz);
+  // some ray of the wavefront culls back faces and the tree has normal cones for that
+  const bool coneWave = TRI && S.bvhCones && __ballot(r.cullBack) != 0;
 #endif
   int ref = 0;
   for (;;) {
@@ -1313,15 +1378,15 @@ __device__ int traceBvh(const DevScene& S, const V3& p, const V3& d, int rayType
       const bool sameNode = TRI && uniformOk && __ballot(ref != uref) == 0;
       if (TRI && sameNode) {
         rt_mask hk[4];
-        bvhNodeSlabsUniform<true>(S, r, uref, negMask, negMask, bestTf, tn, kid, hk);
+        bvhNodeSlabsUniform<true>(S, r, uref, negMask, negMask, bestTf, tn, kid, hk, coneWave);
         RT_DESCEND(hk[0], hk[1], hk[2], hk[3])
-      } else if (TRI && ANYHIT && laneOk) {
+      } else if (TRI && (ANYHIT || coneWave) && laneOk) {
         // an occlusion query's lane at a node of its own: the same binary32
         // planes through vector loads, the copy for its own direction signs
         // (for closest-hit queries the quantised node and a sort were measured
         // faster: 64 instead of 112 bytes per visit)
         rt_mask hk[4];
-        bvhNodeSlabsLane<true>(S, r, ref, myNeg, bestTf, tn, kid, hk);
+        bvhNodeSlabsLane<true>(S, r, ref, myNeg, bestTf, tn, kid, hk, coneWave);
         RT_DESCEND(hk[0], hk[1], hk[2], hk[3])
       } else
 #endif
