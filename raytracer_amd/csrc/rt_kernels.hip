@@ -2485,7 +2485,10 @@ int rt_scene_create(const RtSceneDesc* d, RtScene** out) {
               any = any || out[3] < 1.0f;
             }
           D.bvhCones = any ? 1 : 0;
-          if (const char* e = std::getenv("RT_AMD_CONES")) { if (std::atoi(e) == 0) D.bvhCones = 0; }
+          if (const char* e = std::getenv("RT_AMD_CONES")) {   // 0: off, 1: all rays but camera rays, 2: camera rays too
+            const int v = std::atoi(e);
+            if (v >= 0 && v <= 2 && D.bvhCones) D.bvhCones = v;
+          }
         }
         // Eight copies per node, copy o for rays whose direction is negative on
         // the axes of o's set bits, its children sorted near to far along that

@@ -152,7 +152,8 @@ struct DevScene {
   // (what a slab distance's rounding error grows with, see bvhRaySetup)
   float bvhErrG[3];
   int bvhLaneF;              // 1: bvhF is small enough for 32-bit byte offsets (bvhNodeSlabsLane)
-  int bvhCones;              // 1: the normal cones of bvhF are worth testing (some child of some node can be culled by one)
+  int bvhCones;              // 1: the normal cones of bvhF are worth testing (some child of some node can be culled by
+                             // one) for every ray but camera rays; 2: for camera rays too; 0: not at all
   int bvh_valid;             // 0: empty scene
   int opaque;                // 1: no material transmits (kt == 0 everywhere)
 };
@@ -740,6 +741,7 @@ __device__ __forceinline__ float min2f(float a, float b) {
 typedef unsigned long long rt_mask;
 __device__ __forceinline__ unsigned int pickByMask(unsigned int ifClear, unsigned int ifSet, rt_mask m) {
   unsigned int r;
+  asm("" : "+s"(m));   // a mask the compiler knows the value of must still arrive in a register pair
   asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(ifClear), "v"(ifSet), "s"(m));
   return r;
 }
@@ -820,7 +822,12 @@ __device__ __forceinline__ void bvhRaySetup(const DevScene& S, const V3& p, cons
   r.negy = (d.y < 0.0) & !r.zy;
   r.negz = (d.z < 0.0) & !r.zz;
   // (every ray of the render path has a unit direction; the cones' thresholds leave room for its rounding)
-  const bool cones = r.cullBack && S.bvhCones;
+  // Camera rays look at most of what they meet from its front and get little
+  // for the cone tests (a quarter of a visit's arithmetic): bvhCones == 1 leaves
+  // them out, 2 tests them too.  (Measured and dropped: a wavefront that stops
+  // asking after a few visits without a culled child -- the culls come deep in
+  // the tree, after visits that cull nothing.)
+  const bool cones = r.cullBack && (S.bvhCones > 1 || (S.bvhCones == 1 && rayType != RT_RAY_VISIBILITY));
   r.dfx = cones ? (float)d.x : 0.0f;
   r.dfy = cones ? (float)d.y : 0.0f;
   r.dfz = cones ? (float)d.z : 0.0f;
@@ -1345,7 +1352,7 @@ __device__ int traceBvh(const DevScene& S, const V3& p, const V3& d, int rayType
   // this lane can read the binary32 planes by itself: no axis-parallel component, offsets fit 32 bits
   const bool laneOk = S.bvhLaneF && !(r.zx | r.zy | r.zz);
   // some ray of the wavefront culls back faces and the tree has normal cones for that
-  const bool coneWave = TRI && S.bvhCones && __ballot(r.cullBack) != 0;
+  const bool coneWave = TRI && __ballot((r.dfx != 0.0f) | (r.dfy != 0.0f) | (r.dfz != 0.0f)) != 0;
 #endif
   int ref = 0;
   for (;;) {
