@@ -114,6 +114,7 @@ struct Pool {
 // Shade-point material word: index into DevScene::devMats, or RT_SPM_INTERP when
 // the material was interpolated and lives in the per-point arrays.
 #define RT_PRIM_ANY (-2)                         // shadow query: some occluder in front of the light
+#define RT_PRIM_OUTSIDE (-3)                     // shadow query not run: the point lies outside the spot light's cone
 #define RT_SPM_PENDING 0xffffffffu               // k_surface left the point to k_surface_rest
 #define RT_SPM_INTERP 0x80000000u
 #define RT_SPM_LIT 0x40000000u                   // kd or ks non-zero: lights contribute
@@ -654,7 +655,7 @@ __device__ __forceinline__ void shadowQuery(const DevScene& S, const RtLight& l,
     // acos; in the hair around the cone's edge the query runs.
     const double x = dot(V3(l.orientation), sd * -1);
     if (x < cone[0] && x >= -1.0) {
-      prim = RT_PRIM_NONE;
+      prim = RT_PRIM_OUTSIDE;
       th = 0.0;
       return;
     }
@@ -758,7 +759,7 @@ k_shadow(DevScene S, Pool P) {
       bool anyOccluder;
       const RtLight& l = S.lights[li];
       shadowQuery<FAST, STATS, TRI>(S, l, S.spotCone + 4 * li, Q, prim, th, anyOccluder, tc);
-      if (!P.shT && !anyOccluder && prim != RT_PRIM_NONE && l.type != RT_LIGHT_DIRECTIONAL) {
+      if (!P.shT && !anyOccluder && prim != RT_PRIM_NONE && prim != RT_PRIM_OUTSIDE && l.type != RT_LIGHT_DIRECTIONAL) {
         // The pool of an opaque scene keeps no hit parameter, so the closest
         // occluder is held against the light here, with the expressions of
         // Point/SpotLight::shadowAttenuation (light.cpp:74-80,120-126): it
@@ -811,7 +812,17 @@ __device__ __forceinline__ void shadePoint(const DevScene& S, const Pool& P, int
   const V3 view = hasKs ? normalized(V3(S.eye) - Q) : V3(0.0, 0.0, 0.0);
   for (int li = 0; li < S.n_lights; li++) {
     const size_t o = (size_t)li * P.cap + s;
-    const int sp = P.shPrim[o];
+    int sp = P.shPrim[o];
+    if (sp == RT_PRIM_OUTSIDE) {
+      // k_shadow found the point outside this spot light's cone (with the
+      // comparison lightIntensityFrom would make again): the light's intensity
+      // is (0, 0, 0), and unless a NaN or a negative shininess turns 0 * x into
+      // something (see below) the light adds nothing -- without a square root
+      // taken.  (Q is finite here: the comparison that found the point outside
+      // the cone was true.)
+      if (!anynan(N) && !(hasKs && shin < 0.0)) continue;
+      sp = RT_PRIM_NONE;
+    }
     const double th = P.shT ? P.shT[o] : 0.0;
     V3 L;
     const V3 lightIntensity = lightIntensityFrom<INTPOW>(S, S.lights[li], S.spotCone + 4 * li, Q,
