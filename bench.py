@@ -117,7 +117,7 @@ def csrc_hash():
     return h.hexdigest()[:16]
 
 
-def kd_reference_rate(ds, hs, width, height, kw, count=20000):
+def kd_reference_rate(ds, hs, width, height, kw, count=8000):
     """The caller's KD-tree walked with Scene::intersectKdTree's own rules
     (traversal = reference) on a stratified subset of the same frame: Mrays/s of
     that mode, outside the timed region (the timed frames use the library's BVH)."""
@@ -301,11 +301,38 @@ def main():
                     "flop_per_launch": round(per_launch), "ms_per_launch": round(ms_launch, 4),
                     "launches_per_step": round(n / args.steps, 1), "rays_per_step": round(r),
                     "nodes_per_ray": round(v / max(r, 1.0), 2), "tris_per_ray": round(t / max(r, 1.0), 2),
+                    "nodes_per_ray_exact": v / max(r, 1.0), "tris_per_ray_exact": t / max(r, 1.0),
                     "objects_per_ray": round(o / max(r, 1.0), 3),
                     "Grays_per_s": round(r * args.steps / max(ms, 1e-9) / 1e6, 3)}
 
         kt = kernel_line(V - Vs, T - Ts, O - Os, R - Rs, trace_ms, trace_n)
         kl = kernel_line(Vs, Ts, Os, Rs, lights_ms, lights_n)
+        # What the same rays cost without the normal cones (subtrees that a ray would only meet from behind are
+        # not entered where back faces are culled): the tests a plain closest-hit / occlusion traversal of the
+        # same BVH runs, counted on a second scene handle created with RT_AMD_CONES=0.
+        # Orientation only -- `frac` above prices the tests that WERE run.
+        avoided = None
+        if world == 1 and args.traversal == "fast" and os.environ.get("RT_AMD_CONES") is None:
+            try:
+                os.environ["RT_AMD_CONES"] = "0"
+                ds0 = device.DeviceScene(hs.desc_ptr)
+                del os.environ["RT_AMD_CONES"]
+                s0 = ds0.render_device(ps, packed[0].data_ptr())
+                ds0.close()
+                v0, t0_, o0 = float(s0.nodes_visited - s0.shadow_nodes_visited), float(s0.prims_tested - s0.shadow_prims_tested), \
+                    float(s0.objects_tested - s0.shadow_objects_tested)
+                r0 = float(s0.rays_total - s0.rays_shadow)
+                f0 = (8.0 * v0 + 90.0 * t0_ + 40.0 * o0) / max(r0, 1.0)
+                per_launch0 = f0 * (R - Rs) * args.steps / max(trace_n, 1.0)
+                ach0 = per_launch0 / (kt["ms_per_launch"] * 1e-3) / 1e12 if kt["ms_per_launch"] > 0 else 0.0
+                avoided = {"k_trace_nodes_per_ray_without_culls": round(v0 / max(r0, 1.0), 2),
+                           "k_trace_tris_per_ray_without_culls": round(t0_ / max(r0, 1.0), 2),
+                           "k_trace_flop_per_ray_without_culls": round(f0, 1),
+                           "k_shadow_nodes_per_ray_without_culls": round(float(s0.shadow_nodes_visited) / max(float(s0.rays_shadow), 1.0), 2),
+                           "k_trace_frac_of_fp64_valu_peak_at_that_work": round(ach0 / FP64_VALU_PEAK_TFLOPS, 4)}
+            except Exception as e:
+                os.environ.pop("RT_AMD_CONES", None)
+                avoided = {"error": str(e)}
         traffic = None
         hbm = None
         tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.config)
@@ -335,7 +362,7 @@ def main():
                         "events of the timed steps.  On the fast path only 90 T + 40 O run in binary64 -- the box "
                         "steps 8 V are binary32 packed multiply-adds -- see frac_of_fp64_valu_peak_binary64_terms_only. "
                         "traffic = HBM bytes per launch from the committed counter pass named under hbm",
-                "hbm": hbm, "k_trace": kt, "k_shadow": kl}
+                "hbm": hbm, "k_trace": kt, "k_shadow": kl, "tests_avoided": avoided}
 
     if rank == 0:
         if args.out:
