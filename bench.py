@@ -148,6 +148,10 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget; 0 = skip")
     ap.add_argument("--no-stats-pass", action="store_true")
     ap.add_argument("--out", default=None, help="write the frame as BMP (rank 0)")
+    ap.add_argument("--frames-in-flight", type=int, default=0,
+                    help="frames a rank renders at a time, each on a scene handle and a host thread of its own "
+                         "(0: one per rank up to three -- the thinner a rank's share of the frame, the more of its "
+                         "time is the fixed cost of its recursion levels, which another frame's kernels can fill)")
     args = ap.parse_args()
 
     import torch
@@ -181,13 +185,18 @@ def main():
     ds = device.DeviceScene(hs.desc_ptr)
     if rank == 0:
         log("[bench] rt_scene_create (validation, upload, BVH build): %.2f s" % (time.perf_counter() - t_create))
+    # Frames in flight on this rank: a scene handle serves one caller at a time, so
+    # every frame in flight has a handle (and a host thread) of its own.
+    flights = args.frames_in_flight if args.frames_in_flight > 0 else max(1, min(3, world))
+    handles = [ds] + [device.DeviceScene(hs.desc_ptr) for _ in range(flights - 1)]
     pad_px = parallel.max_shard_pixels(width, height, TILE, TILE, world)
-    # Two packed buffers, used in turn: the gather of frame k may still read its
-    # buffer on the backend's stream while the library renders frame k+1 on its
-    # own streams.  An event per buffer says when the gather that read it is done.
-    packed = [torch.zeros((pad_px, 3), dtype=torch.uint8, device="cuda") for _ in range(2)]
-    packed_free = [None, None]
-    gathered = [torch.empty_like(packed[0]) for _ in range(world)] if (rank == 0 and use_dist) else None
+    # Two packed buffers per handle, used in turn: the gather of a frame may still
+    # read its buffer on the backend's stream while the library renders the
+    # handle's next frame on its own streams.  An event per buffer says when the
+    # gather that read it is done.
+    packed = [[torch.zeros((pad_px, 3), dtype=torch.uint8, device="cuda") for _ in range(2)] for _ in handles]
+    packed_free = [[None, None] for _ in handles]
+    gathered = [torch.empty_like(packed[0][0]) for _ in range(world)] if (rank == 0 and use_dist) else None
     frame = torch.zeros((height, width, 3), dtype=torch.uint8, device="cuda") if rank == 0 else None
     p, keep = host.render_params(width, height, traversal=trav, tile_w=TILE, tile_h=TILE,
                                  shard_index=rank, shard_count=world, out_is_device=True, **kw)
@@ -197,18 +206,22 @@ def main():
     # shard is rendered), then torch events around the gather and the unpack
     phase_events = []
 
-    def step(timed=False):
-        k = frames_done[0] % 2
-        frames_done[0] += 1
-        if packed_free[k] is not None:
-            packed_free[k].synchronize()
+    def render_one(n):
+        # frame n of the run: handle n mod F, that handle's buffers in turn
+        h, k = n % flights, (n // flights) % 2
+        if packed_free[h][k] is not None:
+            packed_free[h][k].synchronize()
         t_r = time.perf_counter()
-        st = ds.render_device(p, packed[k].data_ptr())
-        render_ms = (time.perf_counter() - t_r) * 1e3
+        st = handles[h].render_device(p, packed[h][k].data_ptr())
+        return st, h, k, (time.perf_counter() - t_r) * 1e3
+
+    def deliver(h, k, render_ms, timed):
+        # gather and unpack of a rendered frame: on this thread, in frame order
+        # (every rank issues its collectives in the same order)
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if timed else None
         if ev:
             ev[0].record()
-        bufs = parallel.gather_packed(packed[k], world, rank, force=use_dist, out=gathered)
+        bufs = parallel.gather_packed(packed[h][k], world, rank, force=use_dist, out=gathered)
         if ev:
             ev[1].record()
         if rank == 0:
@@ -218,28 +231,55 @@ def main():
         if ev:
             ev[2].record()
             phase_events.append((render_ms, ev))
-        if packed_free[k] is None:
-            packed_free[k] = torch.cuda.Event()
-        packed_free[k].record()
-        return st
+        if packed_free[h][k] is None:
+            packed_free[h][k] = torch.cuda.Event()
+        packed_free[h][k].record()
+
+    workers = None
+    if flights > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        workers = ThreadPoolExecutor(max_workers=flights)
+
+    def run(nframes, timed=False):
+        """Renders nframes frames, at most `flights` of them at a time; returns their stats."""
+        import collections
+        stats, pending = [], collections.deque()
+        start = frames_done[0]
+        frames_done[0] += nframes
+        nxt = 0
+        while nxt < nframes or pending:
+            while workers is not None and nxt < nframes and len(pending) < flights:
+                pending.append(workers.submit(render_one, start + nxt))
+                nxt += 1
+            if workers is None:
+                res = render_one(start + nxt)
+                nxt += 1
+            else:
+                res = pending.popleft().result()
+            st, h, k, render_ms = res
+            deliver(h, k, render_ms, timed)
+            stats.append(st)
+        return stats
 
     def fence():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    for h in range(1, flights):   # part of an extra handle's set-up: its first frame sizes its pool and its grids
+        handles[h].render_device(p, packed[h][0].data_ptr())
+    run(args.warmup)
     fence()
     t0 = time.perf_counter()
     rays = 0
     sums = np.zeros(6)          # ms_trace, trace launches, ms_lights, lights launches, ms_device, batches
-    for _ in range(args.steps):
-        st = step(timed=True)
+    for st in run(args.steps, timed=True):
         rays += st.rays_total
         sums += [st.ms_trace, st.trace_launches, st.ms_lights, st.lights_launches, st.ms_device, st.batches]
     fence()
     elapsed = time.perf_counter() - t0
+    if workers is not None:
+        workers.shutdown()
     tvals = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
     cvals = torch.tensor([float(rays)] + list(sums), dtype=torch.float64, device="cuda")
     if use_dist:
@@ -278,7 +318,7 @@ def main():
                                        shard_index=rank, shard_count=world, out_is_device=True,
                                        collect_stats=True, **kw)
         torch.cuda.synchronize()
-        sst = ds.render_device(ps, packed[0].data_ptr())
+        sst = ds.render_device(ps, packed[0][0].data_ptr())
         svals = torch.tensor([float(sst.nodes_visited), float(sst.prims_tested), float(sst.objects_tested),
                               float(sst.rays_total), float(sst.shadow_nodes_visited), float(sst.shadow_prims_tested),
                               float(sst.shadow_objects_tested), float(sst.rays_shadow)], dtype=torch.float64, device="cuda")
@@ -317,7 +357,7 @@ def main():
                 os.environ["RT_AMD_CONES"] = "0"
                 ds0 = device.DeviceScene(hs.desc_ptr)
                 del os.environ["RT_AMD_CONES"]
-                s0 = ds0.render_device(ps, packed[0].data_ptr())
+                s0 = ds0.render_device(ps, packed[0][0].data_ptr())
                 ds0.close()
                 v0, t0_, o0 = float(s0.nodes_visited - s0.shadow_nodes_visited), float(s0.prims_tested - s0.shadow_prims_tested), \
                     float(s0.objects_tested - s0.shadow_objects_tested)
@@ -363,6 +403,9 @@ def main():
                         "steps 8 V are binary32 packed multiply-adds -- see frac_of_fp64_valu_peak_binary64_terms_only. "
                         "traffic = HBM bytes per launch from the committed counter pass named under hbm",
                 "hbm": hbm, "k_trace": kt, "k_shadow": kl, "tests_avoided": avoided}
+        if flights > 1:
+            roof["launches_share_the_chip"] = ("%d frames in flight on this rank: a launch's duration includes the time "
+                                               "other frames' kernels held the chip's wave slots" % flights)
 
     if rank == 0:
         if args.out:
@@ -391,7 +434,8 @@ def main():
                                      "uploaded but not traversed" if args.traversal == "fast"
                                      else "reference: the caller's KD-tree, Scene::intersectKdTree's rules"),
                        "kd_reference": kd_ref,
-                       "tile": TILE, "rccl_ranks": world if use_dist else 0, "phases_per_step": phases,
+                       "tile": TILE, "rccl_ranks": world if use_dist else 0, "frames_in_flight": flights,
+                       "phases_per_step": phases,
                        "rays_per_step": round(total_rays / args.steps),
                        "sharding": "interleaved %dx%d tiles over %d rank(s), one gather per frame" % (TILE, TILE, world),
                        "trace_ms_per_step": round(trace_ms / args.steps / world, 3),
@@ -401,7 +445,8 @@ def main():
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
-    ds.close()
+    for h in handles:
+        h.close()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

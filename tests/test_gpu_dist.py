@@ -19,18 +19,23 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_bench_single_rank_through_rccl(built):
+@pytest.mark.parametrize("flights", [1, 2])
+def test_bench_single_rank_through_rccl(built, flights):
+    """bench.py's multi-GPU path with one rank; with two frames in flight the renders
+    come from two scene handles on host threads and the gathers stay in frame order."""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     env = dict(os.environ, RT_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
-           "--gpus", "1", "--steps", "2", "--warmup", "1", "--config", "C1", "--cpu-seconds", "0"]
+           "--gpus", "1", "--steps", "4", "--warmup", "1", "--config", "C1", "--cpu-seconds", "0",
+           "--frames-in-flight", str(flights)]
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=240)
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["roofline"]["k_trace"]["rays_per_step"] > 0
+    assert line["steps"] == 4 and line["config"]["frames_in_flight"] == flights
 
 
 def test_cli_on_one_gpu_through_the_multi_gpu_driver(built, tmp_path):

@@ -375,6 +375,45 @@ def test_one_stream_and_two_streams_give_the_same_frame(built, monkeypatch):
     assert frames[0][2:] == frames[1][2:]
 
 
+def test_two_handles_render_at_once(built):
+    """Frames in flight: two scene handles of one scene, each driven by a host thread
+    of its own, render different frames on one device at the same time; every frame
+    equals the one a handle renders alone."""
+    import threading
+    hs = host.HostScene(text=scenes.mesh_scene(level=3))
+    jit = host.jitter_table(5, 2)
+    settings = [dict(width=160, height=90, depth=3, traversal=abi.RT_TRAVERSE_FAST),
+                dict(width=96, height=54, depth=2, aa_mode=abi.RT_AA_FULL, aa_samples=2, jitter=jit,
+                     traversal=abi.RT_TRAVERSE_FAST, max_batch_samples=2048)]
+    alone = device.DeviceScene(hs.desc_ptr)
+    want = []
+    for kw in settings:
+        p, _ = host.render_params(**kw)
+        rgb, hits, st = alone.render(p)
+        want.append((rgb, hits, _ray_counts(st)))
+    alone.close()
+    handles = [device.DeviceScene(hs.desc_ptr) for _ in settings]
+    got = [[] for _ in settings]
+
+    def work(k):
+        p, _ = host.render_params(**settings[k])
+        for _ in range(6):
+            rgb, hits, st = handles[k].render(p)
+            got[k].append((rgb, hits, _ray_counts(st)))
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(len(settings))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for k in range(len(settings)):
+        assert len(got[k]) == 6
+        for rgb, hits, counts in got[k]:
+            assert np.array_equal(rgb, want[k][0]) and np.array_equal(hits, want[k][1]) and counts == want[k][2]
+    for h in handles:
+        h.close()
+
+
 def test_level_estimates_and_the_redo_of_an_outgrown_batch(built, monkeypatch):
     """A batch that a scene handle has rendered before is queued without reading
     a level's ray count back (grids sized from the counts it had then); the

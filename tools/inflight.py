@@ -41,8 +41,8 @@ for world in worlds:
         for t in ts: t.join()
         torch.cuda.synchronize()
         row.append((time.perf_counter() - t0) * 1e3 / (frames * inflight))
-    if base is None:
+    if base is None and world == 1:
         base = row[0]
-    print("| %d | " % world + " | ".join("%.2f" % ms for ms in row) + " | %.2f |" % (base / world), flush=True)
+    print("| %d | " % world + " | ".join("%.2f" % ms for ms in row) + " | %s |" % ("%.2f" % (base / world) if base else "-"), flush=True)
 for s in scenes:
     s.close()
