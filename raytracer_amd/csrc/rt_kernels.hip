@@ -991,7 +991,11 @@ k_shade(DevScene S, int items, int par, RaySrc R, int depthLeft, Pool P) {
 // through memory (hit -> slot list -> position / normal / material -> ray).
 // Shade-point slots and next-level ray slots come from two tile scans.
 // (the kernel waits for its gathers three quarters of the time: five wavefronts
-// per SIMD, with 28 bytes of spill per lane, beat four without and six with 88)
+// per SIMD, with 44 bytes of spill per lane, beat four without and six with 88.
+// Measured and dropped: holding an entry's stores back until the next entry's
+// loads are issued -- a load behind a store waits for the store too -- needs
+// the next entry's 50 loaded registers beside the 23 waiting to be stored:
+// 8.8 ms instead of 4.4 at five wavefronts per SIMD, 4.5 at four.)
 #ifndef RT_HIT_WAVES
 #define RT_HIT_WAVES 5
 #endif
@@ -1012,16 +1016,25 @@ k_hit(DevScene S, int items, int par, RaySrc R, int level, int depthLeft, int bl
   const long long tileBase = blockIdx.x * perTile;
   if (tileBase >= n) return;   // whole block, uniform
   // pass 1: which rays hit, which of the hits reflect, how many are lit.  Every
-  // entry's loads are independent of the other entries': the loop is unrolled
-  // so that they are in flight together.
+  // entry's loads are independent of the other entries': all primitives are
+  // asked for, then all face words, two waits instead of two per entry (left
+  // to itself the compiler keeps each entry's pair behind the LDS writes of
+  // the entry before).
   unsigned int hitMask = 0, reflMask = 0, myLit = 0;
+  int prims[kHitItems], infos[kHitItems];
+#pragma unroll
+  for (int k = 0; k < kHitItems; k++) {
+    const long long i = tileBase + k * kBlock + threadIdx.x;
+    prims[k] = (k < items && i < n) ? P.hitPrim[i] : RT_PRIM_NONE;
+  }
+#pragma unroll
+  for (int k = 0; k < kHitItems; k++)
+    infos[k] = prims[k] != RT_PRIM_NONE ? S.faceInfo[prims[k] & ~RT_PRIM_FACE] : 0;
 #pragma unroll
   for (int k = 0; k < kHitItems; k++) {
     if (k >= items) break;
-    const long long i = tileBase + k * kBlock + threadIdx.x;
-    const int prim = i < n ? P.hitPrim[i] : RT_PRIM_NONE;
+    const int prim = prims[k], info = infos[k];
     const bool hit = prim != RT_PRIM_NONE;
-    const int info = hit ? S.faceInfo[prim & ~RT_PRIM_FACE] : 0;
     heldPrim[k][threadIdx.x] = prim;
     heldInfo[k][threadIdx.x] = info;
     if (info & RT_FI_LIT) myLit++;

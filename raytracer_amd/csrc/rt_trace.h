@@ -450,23 +450,38 @@ __device__ __forceinline__ bool triTest(const DevTri& T, const V3& lp, const V3&
 // beyond it cannot matter to the caller (it lies behind the best hit / the light).
 __device__ __forceinline__ bool triTestFast(const DevTriFast& T, const V3& lp, const V3& ld, bool cullBack,
                                             double rCull, double& rayT) {
+  // The whole 96-byte record is asked for at once, and pinned in registers
+  // before the first early return: left alone, the compiler sinks each load
+  // behind the returns that come before its first use, and a test then waits
+  // for memory three times in a row (normal, plane constant, corners).  1 % of
+  // a whole frame, 2 % of a thin one.  RT_TRI_LAZY restores that for A/B runs.
   const V3 n(T.n);
+#ifndef RT_TRI_LAZY
+  double dconst = T.dconst, a0 = T.a0, a1 = T.a1, b0 = T.b0, b1 = T.b1, c0 = T.c0, c1 = T.c1, abc2 = T.abc2;
+  int axes = T.axes;
+  asm volatile("" : "+v"(dconst), "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1), "+v"(c0), "+v"(c1), "+v"(abc2), "+v"(axes));
+#else
+  const double dconst = T.dconst;
+#endif
   const double nd = dot(n, ld);
   if (cullBack && nd > 0) return false;
   if (nd == 0) return false;
-  rayT = -(dot(n, lp) + T.dconst) / nd;
+  rayT = -(dot(n, lp) + dconst) / nd;
   if (rayT < RT_EPS) return false;
 #ifndef RT_NO_RCULL
   if (rayT > rCull) return false;
 #endif
   const V3 P = lp + rayT * ld;
-  const double a0 = T.a0, a1 = T.a1, b0 = T.b0, b1 = T.b1, c0 = T.c0, c1 = T.c1;
-  const double p0 = (T.axes & 1) ? P.y : P.x, p1 = (T.axes & 2) ? P.z : P.y;
+#ifdef RT_TRI_LAZY
+  const double a0 = T.a0, a1 = T.a1, b0 = T.b0, b1 = T.b1, c0 = T.c0, c1 = T.c1, abc2 = T.abc2;
+  const int axes = T.axes;
+#endif
+  const double p0 = (axes & 1) ? P.y : P.x, p1 = (axes & 2) ? P.z : P.y;
   const double pbc = fabs((b0 - p0) * (c1 - p1) - (b1 - p1) * (c0 - p0));
   const double apc = fabs((p0 - a0) * (c1 - a1) - (p1 - a1) * (c0 - a0));
   const double abp = fabs((b0 - a0) * (p1 - a1) - (b1 - a1) * (p0 - a0));
   const double s = pbc + apc + abp;
-  return s <= T.abc2 * (1 + RT_EPS) && s >= T.abc2 * (1 - RT_EPS);
+  return s <= abc2 * (1 + RT_EPS) && s >= abc2 * (1 - RT_EPS);
 }
 
 // Local bounding box of a face = componentwise extrema of its vertices
@@ -1046,6 +1061,9 @@ __device__ __forceinline__ void bvhNodeSlabsUniform(const DevScene& S, const Bvh
 // instead of the quantised node's 64, but no byte-to-float conversions, no
 // per-node origin and scale arithmetic, tighter boxes, and children that
 // arrive near to far.  No axis-parallel component (the caller checked).
+#ifndef RT_LANE_CONES_EARLY
+#define RT_LANE_CONES_EARLY 0
+#endif
 template <bool RAW>
 __device__ __forceinline__ void bvhNodeSlabsLane(const DevScene& S, const BvhRay& r, int ref, unsigned int copy,
                                                  float bestTf, float tn[4], int kid[4], rt_mask hit[4],
@@ -1061,6 +1079,13 @@ __device__ __forceinline__ void bvhNodeSlabsLane(const DevScene& S, const BvhRay
   const rt_f4 nZ = *reinterpret_cast<const rt_f4*>(base + (node + oNZ));
   const rt_f4 fZ = *reinterpret_cast<const rt_f4*>(base + (node + (oNZ ^ 16u)));
   const rt_i4 kids = *reinterpret_cast<const rt_i4*>(base + (node + 96u));
+#if RT_LANE_CONES_EARLY
+  rt_f4 cnEarly[4];
+  if (RAW && cones) {
+#pragma unroll
+    for (int c = 0; c < 4; c++) cnEarly[c] = *reinterpret_cast<const rt_f4*>(base + (node + 128u + 16u * c));
+  }
+#endif
   kid[0] = kids.x; kid[1] = kids.y; kid[2] = kids.z; kid[3] = kids.w;
   const rt_f2 ivXY = {r.ivx, r.ivy}, ivZZ = {r.ivz, r.ivz};
   const rt_f2 aX = {r.a0x, r.a1x}, aY = {r.a0y, r.a1y}, aZ = {r.a0z, r.a1z};
@@ -1094,12 +1119,18 @@ __device__ __forceinline__ void bvhNodeSlabsLane(const DevScene& S, const BvhRay
   }
 #undef RT_PKFMA_V
   if (RAW && cones) {   // see bvhNodeSlabsUniform
+#if RT_LANE_CONES_EARLY
+    const rt_f4* cn = cnEarly;
+#else
+    // (all four at once: asked for one by one, only where a child is entered, each load waits for itself)
+    rt_f4 cn[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) cn[c] = *reinterpret_cast<const rt_f4*>(base + (node + 128u + 16u * c));
+#endif
 #pragma unroll
     for (int c = 0; c < 4; c++) {
-      if (hit[c] == 0) continue;
-      const rt_f4 cn = *reinterpret_cast<const rt_f4*>(base + (node + 128u + 16u * c));
-      const float along = fmaf(cn.z, r.dfz, fmaf(cn.y, r.dfy, cn.x * r.dfx));
-      hit[c] &= ~__ballot(along > cn.w);
+      const float along = fmaf(cn[c].z, r.dfz, fmaf(cn[c].y, r.dfy, cn[c].x * r.dfx));
+      hit[c] &= ~__ballot(along > cn[c].w);
     }
   }
 }
