@@ -752,6 +752,8 @@ k_shadow(DevScene S, Pool P) {
   TraceCounters tc{0, 0, 0};
   if (s < nsp) {
     const int li = (int)blockIdx.y;
+    // (Measured: asking for the position together with the material word instead of
+    // behind the test of the word: no change with two lights, 4 % slower with 64.)
     if ((unsigned int)P.spMat[spOff + s] & RT_SPM_LIT) {
       const V3 Q = loadV3(P.spQ, P.cap, spOff + s);
       int prim;
@@ -783,7 +785,7 @@ k_shadow(DevScene S, Pool P) {
 // the diffuse and specular terms, added in the reference's order.
 template <bool INTPOW>
 __device__ __forceinline__ void shadePoint(const DevScene& S, const Pool& P, int s, size_t g, unsigned int mw,
-                                           const V3& Q, const V3& N) {
+                                           const V3& Q, const V3& N, int firstOutcome) {
   const bool interp = (mw & RT_SPM_INTERP) != 0;
   if (!(mw & RT_SPM_LIT)) {
     // an interpolated material's base is already in spShade (k_surface)
@@ -810,9 +812,13 @@ __device__ __forceinline__ void shadePoint(const DevScene& S, const Pool& P, int
   const bool hasKd = !iszero(kd), hasKs = !iszero(ks);
   // the same for every light (material.cpp:66-67)
   const V3 view = hasKs ? normalized(V3(S.eye) - Q) : V3(0.0, 0.0, 0.0);
+  // (a light's query outcome is asked for one light ahead: read where it is
+  // used, every turn of the loop starts with a wait for memory)
+  int spNext = firstOutcome;
   for (int li = 0; li < S.n_lights; li++) {
     const size_t o = (size_t)li * P.cap + s;
-    int sp = P.shPrim[o];
+    int sp = spNext;
+    if (li + 1 < S.n_lights) spNext = P.shPrim[o + P.cap];
     if (sp == RT_PRIM_OUTSIDE) {
       // k_shadow found the point outside this spot light's cone (with the
       // comparison lightIntensityFrom would make again): the light's intensity
@@ -859,7 +865,7 @@ __device__ __forceinline__ void shadePoint(const DevScene& S, const Pool& P, int
 // each spot light) is a small non-negative integer up to rounding, and no
 // material is interpolated: powNearInt instead of pow.
 template <bool INTPOW>
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kBlock, INTPOW ? 4 : 1)   // (without pow the kernel sits at the 128-register step: held to it)
 k_lights(DevScene S, long long queried, Pool P) {
   long long nsp = shadePointsOf(P);
   checkCoverage(P.counters, (long long)gridDim.x * blockDim.x, nsp);
@@ -867,7 +873,8 @@ k_lights(DevScene S, long long queried, Pool P) {
   const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= nsp) return;
   const size_t g = (size_t)P.counters->spOff + s;
-  shadePoint<INTPOW>(S, P, (int)s, g, (unsigned int)P.spMat[g], loadV3(P.spQ, P.cap, g), loadV3(P.spN, P.cap, g));
+  const int firstOutcome = S.n_lights > 0 ? P.shPrim[s] : RT_PRIM_NONE;   // (with the point's own data, before its material is known)
+  shadePoint<INTPOW>(S, P, (int)s, g, (unsigned int)P.spMat[g], loadV3(P.spQ, P.cap, g), loadV3(P.spN, P.cap, g), firstOutcome);
 }
 
 // The secondary rays of RayTracer::traceRay (RayTracer.cpp:152-201).  Reflected rays of a tile are
@@ -1080,6 +1087,9 @@ k_hit(DevScene S, int items, int par, RaySrc R, int level, int depthLeft, int bl
     }
     const int fi = heldPrim[k][threadIdx.x] & ~RT_PRIM_FACE;
     const int info = heldInfo[k][threadIdx.x];
+    // (Measured: asking for everything the entry reads of its face in one go, ahead of
+    // the ray's arithmetic, instead of where each value is first used: 43 registers
+    // held across that arithmetic spill, and the kernel takes twice as long.)
     const double t = P.hitT[i];
     const RayPD ray = rayAt(S, R, (int)i);
     Surface sf;
