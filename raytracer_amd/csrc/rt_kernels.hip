@@ -1170,22 +1170,63 @@ k_resolve(DevScene S, FrameMap fm, SlotBase first, int nPixels, int ppb, int bla
   const int pix0 = blockIdx.x * ppb;
   const int npix = min(ppb, nPixels - pix0);
   const size_t base = (size_t)pix0 * ns;
-  for (int e = threadIdx.x; e < npix * ns; e += kBlock) {
-    // the sample's colour: that of its level-0 shade point, or the background's
-    // (black, or what k_background left in the ray's slot)
-    const int sp = P.primarySp[base + e];
-    V3 c = sp >= 0 ? combinedColour(S, P, (size_t)sp) : blackMiss ? V3(0.0, 0.0, 0.0) : loadV3(P.rayI, P.cap, base + e);
-    if (c.x < 0) c.x = 0.0;
-    if (c.x > 1) c.x = 1.0;
-    if (c.y < 0) c.y = 0.0;
-    if (c.y > 1) c.y = 1.0;
-    if (c.z < 0) c.z = 0.0;
-    if (c.z > 1) c.z = 1.0;
+  // A thread's samples (at most kResolveSamples / kBlock of them) go through the
+  // chain sample -> shade point -> its colour and child ray -> the child's colour
+  // side by side: each link is asked for all samples before the next link is.
+  constexpr int kPer = kResolveSamples / kBlock;
+  const int nSamples = npix * ns;
+  int sp[kPer], cr[kPer];
+  V3 c[kPer];
+#pragma unroll
+  for (int j = 0; j < kPer; j++) {
+    const int e = threadIdx.x + j * kBlock;
+    sp[j] = e < nSamples ? P.primarySp[base + e] : -1;
+  }
+#pragma unroll
+  for (int j = 0; j < kPer; j++) {
+    const int e = threadIdx.x + j * kBlock;
+    cr[j] = -1;
+    if (sp[j] >= 0) {
+      c[j] = loadV3(P.spShade, P.cap, (size_t)sp[j]);
+      cr[j] = P.spChildRefl[sp[j]];
+    } else if (e < nSamples && !blackMiss) {
+      // the background's colour: what k_background left in the ray's slot
+      c[j] = loadV3(P.rayI, P.cap, base + e);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < kPer; j++) {
+    const int e = threadIdx.x + j * kBlock;
+    if (e >= nSamples) continue;
+    if (sp[j] >= 0 && !(S.opaque && cr[j] < 0)) {
+      // intensity = shade; += kr * traceRay(reflected); += kt * traceRay(refracted) (combinedColour, from its colour on)
+      const size_t g = (size_t)sp[j];
+      const int ct = S.opaque ? -1 : P.spChildRefr[g];
+      if (cr[j] >= 0 || ct >= 0) {
+        const unsigned int mw = (unsigned int)P.spMat[g];
+        const bool interp = (mw & RT_SPM_INTERP) != 0;
+        const DevMat* dm = interp ? nullptr : &S.devMats[mw & RT_SPM_INDEX];
+        if (cr[j] >= 0) c[j] = c[j] + prod(interp ? loadV3(P.spKr, P.cap, g) : V3(dm->kr), loadV3(P.rayI, P.cap, (size_t)cr[j]));
+        if (ct >= 0) c[j] = c[j] + prod(interp ? loadV3(P.spKt, P.cap, g) : V3(dm->kt), loadV3(P.rayI, P.cap, (size_t)ct));
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < kPer; j++) {
+    const int e = threadIdx.x + j * kBlock;
+    if (e >= nSamples) continue;
+    V3 col = c[j];   // (a sample that hit nothing under a black background: (0, 0, 0), as V3 starts)
+    if (col.x < 0) col.x = 0.0;
+    if (col.x > 1) col.x = 1.0;
+    if (col.y < 0) col.y = 0.0;
+    if (col.y > 1) col.y = 1.0;
+    if (col.z < 0) col.z = 0.0;
+    if (col.z > 1) col.z = 1.0;
     const int pl = (int)fastDiv((unsigned int)e, fm.dNs), k = e - pl * ns;
     const int o = pl * pitch + k;
-    lds[0][o] = c.x;
-    lds[1][o] = c.y;
-    lds[2][o] = c.z;
+    lds[0][o] = col.x;
+    lds[1][o] = col.y;
+    lds[2][o] = col.z;
     if (k == 0 && hitId) ldsId[pl] = P.primaryId[base + e];
   }
   __syncthreads();
