@@ -740,7 +740,9 @@ __device__ __forceinline__ V3 lightIntensityFrom(const DevScene& S, const RtLigh
 // One thread per (light, shade point): the shadow query, nothing else, so that
 // the kernel's register budget is the traversal's (the Phong terms need pow and
 // acos, whose double-precision library code would nearly double it and halve
-// the wavefronts that hide the traversal's memory latency).
+// the wavefronts that hide the traversal's memory latency).  (Measured: a thread
+// that reads its point once and asks 2 .. 16 lights in a loop -- 64 lights:
+// 10.2 -> 9.9 ms at 8 per thread; 2 lights: 20.4 -> 20.6 ms.  Not kept.)
 template <bool FAST, bool STATS, bool TRI>
 __global__ void RT_TRACE_BOUNDS(FAST, TRI)
 k_shadow(DevScene S, Pool P) {
