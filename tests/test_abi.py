@@ -66,3 +66,13 @@ def test_product_path_does_not_reference_the_oracle():
             if f.endswith((".py", ".cpp", ".h", ".hip")):
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "oracle" not in text.lower(), os.path.join(dirpath, f)
+
+
+def test_kernel_code_hashes_name_the_benchmark_kernel(built):
+    """bench.py ties a committed counter pass to the machine code of the kernel it measured: the built
+    library must yield one hash per kernel, and exactly one kernel must carry the closest-hit symbol."""
+    import bench
+    hashes = bench.kernel_code_hashes()
+    assert len(hashes) >= 30 and all(len(v) == 16 for v in hashes.values())
+    assert len([k for k in hashes if bench.K_TRACE_SYMBOL in k]) == 1
+    assert any("k_resolve" in k for k in hashes) and any("k_hit" in k for k in hashes)

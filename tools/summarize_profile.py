@@ -104,6 +104,11 @@ def main():
     sys.path.insert(0, ROOT)
     import bench
     out = {"source": "profiles/%s_pmc_summary.md" % tag, "commit": commit, "csrc_sha": bench.csrc_hash(), "kernels": traffic}
+    try:   # per kernel, so that a later change to another kernel does not orphan these counters
+        out["kernel_code_sha"] = bench.kernel_code_hashes()
+    except Exception as e:
+        out["kernel_code_sha"] = None
+        print("no machine-code hashes: %s" % e, file=sys.stderr)
     if kt:
         out["k_trace_waves_per_simd"] = kt["waves_per_simd"]
         out["k_trace_hbm_bytes_per_launch"] = kt["read_bytes_per_launch"] + kt["write_bytes_per_launch"]
