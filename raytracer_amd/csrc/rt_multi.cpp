@@ -69,7 +69,7 @@ int ensureBytes(unsigned char** buf, size_t* have, size_t bytes) {
   return RT_OK;
 }
 
-// One device's part of a frame: render its tiles, hand them to the first device.
+// One device's part of a frame: render its tiles into the device's packed buffer.
 void renderShard(RtMulti* m, int r, const RtRenderParams* params, const std::vector<size_t>* shardBytes) {
   Rank& k = m->ranks[(size_t)r];
   const int n = (int)m->ranks.size();
@@ -89,26 +89,43 @@ void renderShard(RtMulti* m, int r, const RtRenderParams* params, const std::vec
   const size_t bytes = (*shardBytes)[(size_t)r];
   if (bytes > 0) {
     if (ensureBytes(&k.packed, &k.packedBytes, bytes) != RT_OK) return bail(RT_ERR_NOMEM, g_multiError);
+    // (returns when the shard is rendered: the buffer is complete for the exchange)
     if (rt_render(k.scene, &p, k.packed, nullptr, &k.stats) != RT_OK) return bail(RT_ERR_DEVICE, rt_last_error());
   }
-  // The frame's one exchange: every other device sends its packed tiles to the
-  // first, which posts one receive per sender -- all inside one group, so the
-  // transfers of the seven links run side by side.  (A device never sends to
-  // itself: the first device's tiles are unpacked from where they were rendered.)
-  if (n > 1) {
-    ncclResult_t nr = ncclGroupStart();
-    if (nr == ncclSuccess && r == 0) {
-      for (int q = 1; q < n && nr == ncclSuccess; q++)
-        if ((*shardBytes)[(size_t)q] > 0)
-          nr = ncclRecv(m->landing[(size_t)q], (*shardBytes)[(size_t)q], ncclUint8, q, k.comm, k.stream);
-    } else if (nr == ncclSuccess && bytes > 0) {
-      nr = ncclSend(k.packed, bytes, ncclUint8, 0, k.comm, k.stream);
-    }
-    const ncclResult_t ne = ncclGroupEnd();
-    if (nr != ncclSuccess || ne != ncclSuccess)
-      return bail(RT_ERR_DEVICE, std::string("RCCL exchange: ") + ncclGetErrorString(nr != ncclSuccess ? nr : ne));
-    if (hipStreamSynchronize(k.stream) != hipSuccess) return bail(RT_ERR_DEVICE, "exchange stream failed");
+}
+
+// The frame's one exchange, after every device has rendered its shard: every
+// other device sends its packed tiles to the first, which posts one receive per
+// sender -- all inside one group, so the transfers of the seven links run side
+// by side.  (A device never sends to itself: the first device's tiles are
+// unpacked from where they were rendered.)  Issued by the calling thread for
+// all devices, and only when every shard was rendered: a device that failed
+// cannot leave the others waiting for a transfer that never comes.
+int exchangeShards(RtMulti* m, const std::vector<size_t>& shardBytes) {
+  const int n = (int)m->ranks.size();
+  if (n < 2) return RT_OK;
+  ncclResult_t nr = ncclGroupStart();
+  for (int q = 1; q < n && nr == ncclSuccess; q++) {
+    const size_t bytes = shardBytes[(size_t)q];
+    if (bytes == 0) continue;
+    Rank& k0 = m->ranks[0];
+    Rank& kq = m->ranks[(size_t)q];
+    // (each call with its communicator's device current, as for any other work queued on that device's stream)
+    if (hipSetDevice(k0.device) != hipSuccess) { nr = ncclUnhandledCudaError; break; }
+    nr = ncclRecv(m->landing[(size_t)q], bytes, ncclUint8, q, k0.comm, k0.stream);
+    if (nr != ncclSuccess) break;
+    if (hipSetDevice(kq.device) != hipSuccess) { nr = ncclUnhandledCudaError; break; }
+    nr = ncclSend(kq.packed, bytes, ncclUint8, 0, kq.comm, kq.stream);
   }
+  const ncclResult_t ne = ncclGroupEnd();   // (always closed, also after a failed call inside the group)
+  if (nr != ncclSuccess || ne != ncclSuccess)
+    return failMulti(RT_ERR_DEVICE, std::string("RCCL exchange: ") + ncclGetErrorString(nr != ncclSuccess ? nr : ne));
+  for (int q = 0; q < n; q++) {
+    Rank& k = m->ranks[(size_t)q];
+    MULTI_HIP(hipSetDevice(k.device));
+    MULTI_HIP(hipStreamSynchronize(k.stream));
+  }
+  return RT_OK;
 }
 
 }  // namespace
@@ -233,6 +250,10 @@ int rt_multi_render(RtMulti* m, const RtRenderParams* params, unsigned char* rgb
       (void)hipSetDevice(cur);
       return failMulti(k.rc, "device " + std::to_string(k.device) + ": " + k.error);
     }
+  {
+    const int rc = exchangeShards(m, shardBytes);
+    if (rc != RT_OK) { (void)hipSetDevice(cur); return rc; }
+  }
   // packed tiles -> frame, on the first device, then the frame to the caller
   Rank& k0 = m->ranks[0];
   MULTI_HIP(hipSetDevice(k0.device));
