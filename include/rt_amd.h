@@ -307,6 +307,29 @@ int rt_edge_mask(const unsigned char* rgb8, int width, int height, int cutoff,
  * (|delta| <= 1e-12).  Host pointers. */
 int rt_test_pow_near_int(int count, const double* x, int n, double delta, double* out);
 
+/* Test hook, host only (no device call): builds the acceleration structure of
+ * RT_TRAVERSE_FAST over n_tris world-space triangles (vertices: 9 doubles each;
+ * normals: the face normal TrimeshFace::intersectLocal would use, 3 doubles
+ * each, src/SceneObjects/trimesh.cpp:93-104) by the steps rt_scene_create takes
+ * for a scene of identity-transform meshes -- binary SAH tree, 4-wide nodes
+ * with 8-bit planes, binary32 child boxes, a normal cone per child, eight
+ * sign-ordered copies per node -- and checks what the traversal relies on.
+ * report[0..15]: [0] 4-wide nodes, [1] their depth, [2] binary nodes,
+ * [3] triangles not found exactly once below the root (or unreachable nodes,
+ * or a child whose triangles are not one contiguous run), [4] / [5] (triangle,
+ * ancestor child) pairs with a vertex outside the child's binary32 / decoded
+ * 8-bit box, [6] pairs with the triangle's normal outside the child's cone,
+ * [7] sampled directions that the visit's binary32 cone test turns away from a
+ * child although a triangle below it has normal . direction <= 0 (the reference
+ * would have tested it), [8] sampled directions turned away in all, [9] node
+ * copies that are not a reordering of the node's first copy, [10] copies whose
+ * children are not sorted near to far along the copy's diagonal, [11] unused
+ * slots without an inverted box, [12] children with a cone narrow enough to
+ * cull by, [13] leaves with more than max_leaf (1..8) triangles.  A correct
+ * build has zeros in [3..7], [9..11] and [13]. */
+int rt_test_bvh_invariants(int n_tris, const double* vertices, const double* normals, int max_leaf,
+                           long long* report);
+
 const char* rt_last_error(void);
 int rt_abi_version(void);
 

@@ -117,6 +117,7 @@ RT_AMD_SYMBOLS = {
                                    C.c_longlong, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(RtStats)]),
     "rt_patch_flagged": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rt_test_pow_near_int": (C.c_int, [C.c_int, PD, C.c_int, C.c_double, PD]),
+    "rt_test_bvh_invariants": (C.c_int, [C.c_int, PD, PD, C.c_int, C.POINTER(C.c_longlong)]),
     "rt_last_error": (C.c_char_p, []),
     "rt_abi_version": (C.c_int, []),
 }

@@ -1638,6 +1638,155 @@ int treeDepth(const RtSceneDesc& d, int root, int itemLimit, std::string& err) {
   return best;
 }
 
+// Appends the null triangle (normal zero: every ray is parallel to it and
+// rejected) and points every unused child slot at a leaf that holds it.  False:
+// the array has outgrown the leaf encoding.
+bool addNullLeaf(std::vector<DevTri>& ordered, std::vector<rtbvh::Node4>& nodes4) {
+  DevTri nullTri;
+  std::memset(&nullTri, 0, sizeof nullTri);
+  nullTri.axes = 0 | (1 << 2) | 16;
+  ordered.push_back(nullTri);
+  if (ordered.size() >= (1u << 27)) return false;
+  const int32_t nullLeaf = ~(int32_t)(((int32_t)(ordered.size() - 1) << 3) | 0);
+  for (rtbvh::Node4& n4 : nodes4)
+    for (int c = 0; c < 4; c++)
+      if (n4.child[c] == rtbvh::kEmptyChild) n4.child[c] = nullLeaf;
+  return true;
+}
+
+// What the kernels of triangle-only scenes read instead of the quantised nodes
+// (DevBvhNodeF): per 4-wide node its child boxes as binary32 planes, the normal
+// cone of every child, and all of it eight times over, once per combination of
+// direction signs with the children sorted near to far.  `ordered` is the
+// leaf-ordered triangle array with the null triangle of the unused slots at its
+// end; anyCone: some child has a cone narrow enough to cull by.
+void buildNodeCopies(const std::vector<rtbvh::Node4>& nodes4, const std::vector<rtbvh::Collapser::Tight>& tightBoxes,
+                     const std::vector<DevTri>& ordered, std::vector<DevBvhNodeF>& fn, bool& anyCone) {
+  struct {
+    const std::vector<rtbvh::Node4>& nodes;
+    const std::vector<rtbvh::Collapser::Tight>& tight;
+  } wide{nodes4, tightBoxes};
+  // Normal cone of every child of every node (see DevBvhNodeF::cone).  The
+  // binary builder partitions the triangle array in place, so the
+  // triangles below a child are a contiguous run of the leaf-ordered
+  // array: axis = the normalised sum of the run's unit normals, opening =
+  // the widest angle any of them makes with it.
+  struct Run { int lo, hi; };
+  std::vector<std::array<float, 16>> cones(wide.nodes.size());
+  {
+    std::vector<std::array<double, 3>> unit(ordered.size());
+    std::vector<char> valid(ordered.size(), 0);
+    for (size_t t = 0; t < ordered.size(); t++) {
+      const double* nn = ordered[t].n;
+      const double len = std::sqrt(nn[0] * nn[0] + nn[1] * nn[1] + nn[2] * nn[2]);
+      // a triangle without a direction (null or NaN normal) is never hit, whatever the ray
+      if (len > 0.0 && std::isfinite(len)) {
+        unit[t] = {nn[0] / len, nn[1] / len, nn[2] / len};
+        valid[t] = 1;
+      }
+    }
+    auto coneOf = [&](Run r, float* out) {
+      double ax[3] = {0.0, 0.0, 0.0};
+      for (int t = r.lo; t < r.hi; t++)
+        if (valid[(size_t)t]) for (int a = 0; a < 3; a++) ax[a] += unit[(size_t)t][a];
+      const double al = std::sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
+      out[0] = out[1] = out[2] = 0.0f;
+      out[3] = 2.0f;
+      if (!(al > 1e-9)) return;
+      for (int a = 0; a < 3; a++) { ax[a] /= al; out[a] = (float)ax[a]; }
+      // The widest angle a normal of the run makes with the axis AS STORED (binary32, so only nearly of unit
+      // length), by its sine from the cross product: the sine of a narrow cone cannot be had from the cosine
+      // (1 - cos is below the rounding of the axis once the angle is under a few 1e-4, which coplanar
+      // neighbours of a terrain are).
+      const double sx = out[0], sy = out[1], sz = out[2];
+      const double sl = std::sqrt(sx * sx + sy * sy + sz * sz);
+      double cosMin = 1.0, sinMax = 0.0;
+      for (int t = r.lo; t < r.hi; t++)
+        if (valid[(size_t)t]) {
+          const double* u = unit[(size_t)t].data();
+          cosMin = std::min(cosMin, (sx * u[0] + sy * u[1] + sz * u[2]) / sl);
+          const double cx = sy * u[2] - sz * u[1], cy = sz * u[0] - sx * u[2], cz = sx * u[1] - sy * u[0];
+          sinMax = std::max(sinMax, std::sqrt(cx * cx + cy * cy + cz * cz) / sl);
+        }
+      if (cosMin <= 0.05) return;   // wider than 87 degrees: nothing to gain
+      // sin(theta), and room for the binary32 roundings of this bound, of the direction and of the visit's dot product
+      out[3] = (float)(sinMax * (1.0 + 1.0e-4) + 1.0e-5);
+      if (out[3] >= 1.0f) out[3] = 2.0f;
+    };
+    // runs bottom-up: the children of a node come after it in `wide.nodes` (the collapser appends them).
+    // An empty run marks a child without triangles of its own (an unused slot, which points at the
+    // null triangle at the end of the array; a non-mesh object).
+    const int nullTriangle = (int)ordered.size() - 1;
+    std::vector<std::array<Run, 4>> runs(wide.nodes.size());
+    std::vector<Run> whole(wide.nodes.size());
+    for (size_t i = wide.nodes.size(); i-- > 0;) {
+      Run all{INT32_MAX, -1};
+      for (int c = 0; c < 4; c++) {
+        const int32_t ref = wide.nodes[i].child[c];
+        Run r{0, -1};
+        if (ref >= 0) {
+          r = whole[(size_t)ref];
+        } else {
+          const int x = ~ref;
+          if (!(x & rtbvh::kObjectBit) && (x >> 3) != nullTriangle) r = Run{x >> 3, (x >> 3) + (x & 7) + 1};
+        }
+        runs[i][(size_t)c] = r;
+        if (r.hi > r.lo) { all.lo = std::min(all.lo, r.lo); all.hi = std::max(all.hi, r.hi); }
+      }
+      whole[i] = all;
+    }
+    bool any = false;
+    for (size_t i = 0; i < wide.nodes.size(); i++)
+      for (int c = 0; c < 4; c++) {
+        float* out = &cones[i][(size_t)(4 * c)];
+        out[0] = out[1] = out[2] = 0.0f;
+        out[3] = 2.0f;
+        const Run r = runs[i][(size_t)c];
+        if (r.hi > r.lo) coneOf(r, out);
+        any = any || out[3] < 1.0f;
+      }
+    anyCone = any;
+  }
+  // Eight copies per node, copy o for rays whose direction is negative on
+  // the axes of o's set bits, its children sorted near to far along that
+  // diagonal (box centres; unused slots, whose boxes are inverted, last).
+  fn.resize(wide.nodes.size() * 8);
+  for (size_t i = 0; i < wide.nodes.size(); i++) {
+    const rtbvh::Node4& n4 = wide.nodes[i];
+    // (the boxes as the builder made them, not their 8-bit quantised form:
+    // this path has room for them, and tighter boxes cull more)
+    const rtbvh::Collapser::Tight& tb = wide.tight[i];
+    float blo[3][4], bhi[3][4];
+    for (int c = 0; c < 4; c++)
+      for (int a = 0; a < 3; a++) { blo[a][c] = tb.lo[a][c]; bhi[a][c] = tb.hi[a][c]; }
+    for (int o = 0; o < 8; o++) {
+      double key[4];
+      int order[4] = {0, 1, 2, 3};
+      for (int c = 0; c < 4; c++) {
+        bool inverted = false;
+        double k = 0.0;
+        for (int a = 0; a < 3; a++) {
+          inverted |= blo[a][c] > bhi[a][c];
+          const double centre = 0.5 * ((double)blo[a][c] + (double)bhi[a][c]);
+          k += ((o >> a) & 1) ? -centre : centre;
+        }
+        key[c] = inverted ? std::numeric_limits<double>::infinity() : k;
+      }
+      std::stable_sort(order, order + 4, [&](int x, int y) { return key[x] < key[y]; });
+      DevBvhNodeF& F = fn[i * 8 + (size_t)o];
+      std::memset(&F, 0, sizeof F);
+      float* lo[3] = {F.lo_x, F.lo_y, F.lo_z};
+      float* hi[3] = {F.hi_x, F.hi_y, F.hi_z};
+      for (int j = 0; j < 4; j++) {
+        const int c = order[j];
+        F.child[j] = n4.child[c];
+        for (int a = 0; a < 3; a++) { lo[a][j] = blo[a][c]; hi[a][j] = bhi[a][c]; }
+        for (int a = 0; a < 4; a++) F.cone[j][a] = cones[i][(size_t)(4 * c + a)];
+      }
+    }
+  }
+}
+
 int ensurePool(RtScene* sc, size_t cap) {
   const size_t nl = (size_t)std::max(1, sc->nLights);
   if (sc->pool.cap >= cap && sc->poolLights >= nl) return RT_OK;
@@ -2448,17 +2597,7 @@ int rt_scene_create(const RtSceneDesc* d, RtScene** out) {
       // zero: every ray is parallel to it and rejected), so that the traversal
       // needs no "is this slot used" test next to the slab test of its
       // inverted box.
-      {
-        DevTri nullTri;
-        std::memset(&nullTri, 0, sizeof nullTri);
-        nullTri.axes = 0 | (1 << 2) | 16;
-        ordered.push_back(nullTri);
-        if (ordered.size() >= (1u << 27)) return fail(RT_ERR_UNSUPPORTED, "too many triangles for the BVH leaf encoding");
-        const int32_t nullLeaf = ~(int32_t)(((int32_t)(ordered.size() - 1) << 3) | 0);
-        for (rtbvh::Node4& n4 : wide.nodes)
-          for (int c = 0; c < 4; c++)
-            if (n4.child[c] == rtbvh::kEmptyChild) n4.child[c] = nullLeaf;
-      }
+      if (!addNullLeaf(ordered, wide.nodes)) return fail(RT_ERR_UNSUPPORTED, "too many triangles for the BVH leaf encoding");
       DevTri* bt; HIP_TRY(upload(ordered.data(), ordered.size(), &bt)); keep(bt); D.bvhTris = bt;
       if (sc->triOnly) {
         std::vector<DevTriFast> fastTris(ordered.size());
@@ -2489,119 +2628,14 @@ int rt_scene_create(const RtSceneDesc* d, RtScene** out) {
         // node, sixteen times the quantised node array)
         // the same child boxes decoded to binary32 planes, outward rounded
         static_assert(sizeof(DevBvhNodeF) == RT_BVHF_BYTES, "float BVH node size");
-        // Normal cone of every child of every node (see DevBvhNodeF::cone).  The
-        // binary builder partitions the triangle array in place, so the
-        // triangles below a child are a contiguous run of the leaf-ordered
-        // array: axis = the normalised sum of the run's unit normals, opening =
-        // the widest angle any of them makes with it.
-        struct Run { int lo, hi; };
-        std::vector<std::array<float, 16>> cones(wide.nodes.size());
+        std::vector<DevBvhNodeF> fn;
         {
-          std::vector<std::array<double, 3>> unit(ordered.size());
-          std::vector<char> valid(ordered.size(), 0);
-          for (size_t t = 0; t < ordered.size(); t++) {
-            const double* nn = ordered[t].n;
-            const double len = std::sqrt(nn[0] * nn[0] + nn[1] * nn[1] + nn[2] * nn[2]);
-            // a triangle without a direction (null or NaN normal) is never hit, whatever the ray
-            if (len > 0.0 && std::isfinite(len)) {
-              unit[t] = {nn[0] / len, nn[1] / len, nn[2] / len};
-              valid[t] = 1;
-            }
-          }
-          auto coneOf = [&](Run r, float* out) {
-            double ax[3] = {0.0, 0.0, 0.0};
-            for (int t = r.lo; t < r.hi; t++)
-              if (valid[(size_t)t]) for (int a = 0; a < 3; a++) ax[a] += unit[(size_t)t][a];
-            const double al = std::sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
-            out[0] = out[1] = out[2] = 0.0f;
-            out[3] = 2.0f;
-            if (!(al > 1e-9)) return;
-            for (int a = 0; a < 3; a++) { ax[a] /= al; out[a] = (float)ax[a]; }
-            double cosMin = 1.0;
-            for (int t = r.lo; t < r.hi; t++)
-              if (valid[(size_t)t])
-                cosMin = std::min(cosMin, (double)out[0] * unit[(size_t)t][0] + (double)out[1] * unit[(size_t)t][1] +
-                                              (double)out[2] * unit[(size_t)t][2]);
-            if (cosMin <= 0.05) return;   // wider than 87 degrees: nothing to gain
-            // sin(theta), and room for the binary32 roundings of axis, direction and dot product
-            const double sinMax = std::sqrt(std::max(0.0, 1.0 - cosMin * cosMin));
-            out[3] = (float)(sinMax * (1.0 + 1.0e-4) + 1.0e-5);
-            if (out[3] >= 1.0f) out[3] = 2.0f;
-          };
-          // runs bottom-up: the children of a node come after it in `wide.nodes` (the collapser appends them).
-          // An empty run marks a child without triangles of its own (an unused slot, which points at the
-          // null triangle at the end of the array; a non-mesh object).
-          const int nullTriangle = (int)ordered.size() - 1;
-          std::vector<std::array<Run, 4>> runs(wide.nodes.size());
-          std::vector<Run> whole(wide.nodes.size());
-          for (size_t i = wide.nodes.size(); i-- > 0;) {
-            Run all{INT32_MAX, -1};
-            for (int c = 0; c < 4; c++) {
-              const int32_t ref = wide.nodes[i].child[c];
-              Run r{0, -1};
-              if (ref >= 0) {
-                r = whole[(size_t)ref];
-              } else {
-                const int x = ~ref;
-                if (!(x & rtbvh::kObjectBit) && (x >> 3) != nullTriangle) r = Run{x >> 3, (x >> 3) + (x & 7) + 1};
-              }
-              runs[i][(size_t)c] = r;
-              if (r.hi > r.lo) { all.lo = std::min(all.lo, r.lo); all.hi = std::max(all.hi, r.hi); }
-            }
-            whole[i] = all;
-          }
-          bool any = false;
-          for (size_t i = 0; i < wide.nodes.size(); i++)
-            for (int c = 0; c < 4; c++) {
-              float* out = &cones[i][(size_t)(4 * c)];
-              out[0] = out[1] = out[2] = 0.0f;
-              out[3] = 2.0f;
-              const Run r = runs[i][(size_t)c];
-              if (r.hi > r.lo && sc->triOnly) coneOf(r, out);
-              any = any || out[3] < 1.0f;
-            }
-          D.bvhCones = any ? 1 : 0;
+          bool anyCone = false;
+          buildNodeCopies(wide.nodes, wide.tight, ordered, fn, anyCone);
+          D.bvhCones = anyCone ? 1 : 0;
           if (const char* e = std::getenv("RT_AMD_CONES")) {   // 0: off, 1: all rays but camera rays, 2: camera rays too
             const int v = std::atoi(e);
             if (v >= 0 && v <= 2 && D.bvhCones) D.bvhCones = v;
-          }
-        }
-        // Eight copies per node, copy o for rays whose direction is negative on
-        // the axes of o's set bits, its children sorted near to far along that
-        // diagonal (box centres; unused slots, whose boxes are inverted, last).
-        std::vector<DevBvhNodeF> fn(wide.nodes.size() * 8);
-        for (size_t i = 0; i < wide.nodes.size(); i++) {
-          const rtbvh::Node4& n4 = wide.nodes[i];
-          // (the boxes as the builder made them, not their 8-bit quantised form:
-          // this path has room for them, and tighter boxes cull more)
-          const rtbvh::Collapser::Tight& tb = wide.tight[i];
-          float blo[3][4], bhi[3][4];
-          for (int c = 0; c < 4; c++)
-            for (int a = 0; a < 3; a++) { blo[a][c] = tb.lo[a][c]; bhi[a][c] = tb.hi[a][c]; }
-          for (int o = 0; o < 8; o++) {
-            double key[4];
-            int order[4] = {0, 1, 2, 3};
-            for (int c = 0; c < 4; c++) {
-              bool inverted = false;
-              double k = 0.0;
-              for (int a = 0; a < 3; a++) {
-                inverted |= blo[a][c] > bhi[a][c];
-                const double centre = 0.5 * ((double)blo[a][c] + (double)bhi[a][c]);
-                k += ((o >> a) & 1) ? -centre : centre;
-              }
-              key[c] = inverted ? std::numeric_limits<double>::infinity() : k;
-            }
-            std::stable_sort(order, order + 4, [&](int x, int y) { return key[x] < key[y]; });
-            DevBvhNodeF& F = fn[i * 8 + (size_t)o];
-            std::memset(&F, 0, sizeof F);
-            float* lo[3] = {F.lo_x, F.lo_y, F.lo_z};
-            float* hi[3] = {F.hi_x, F.hi_y, F.hi_z};
-            for (int j = 0; j < 4; j++) {
-              const int c = order[j];
-              F.child[j] = n4.child[c];
-              for (int a = 0; a < 3; a++) { lo[a][j] = blo[a][c]; hi[a][j] = bhi[a][c]; }
-              for (int a = 0; a < 4; a++) F.cone[j][a] = cones[i][(size_t)(4 * c + a)];
-            }
           }
         }
         DevBvhNodeF* fp;
@@ -3155,6 +3189,241 @@ int rt_test_pow_near_int(int count, const double* x, int n, double delta, double
   k_pow_near_int<<<gridFor(count), kBlock, 0, 0>>>(count, in.as<double>(), n, delta, res.as<double>());
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpy(out, res.p, (size_t)count * sizeof(double), hipMemcpyDeviceToHost));
+  return RT_OK;
+}
+
+int rt_test_bvh_invariants(int n_tris, const double* vertices, const double* normals, int max_leaf, long long* report) {
+  if (n_tris < 1 || !vertices || !normals || !report || max_leaf < 1 || max_leaf > 8)
+    return fail(RT_ERR_INVALID, "bad argument");
+  for (int k = 0; k < 16; k++) report[k] = 0;
+  // the structure, by the steps of rt_scene_create for a scene of identity-transform meshes
+  std::vector<rtbvh::Prim> prims((size_t)n_tris);
+  for (int f = 0; f < n_tris; f++) {
+    rtbvh::Prim& pr = prims[(size_t)f];
+    pr.box.reset();
+    for (int k = 0; k < 3; k++) pr.box.grow(vertices + 9 * (size_t)f + 3 * k);
+    for (int a = 0; a < 3; a++) pr.c[a] = 0.5 * (pr.box.lo[a] + pr.box.hi[a]);
+    pr.id = f;
+  }
+  rtbvh::Builder bvh;
+  rtbvh::Collapser wide;
+  bvh.maxLeaf = max_leaf;
+  if (!bvh.build(prims)) return fail(RT_ERR_INVALID, "empty scene");
+  wide.run(bvh.nodes);
+  std::vector<DevTri> ordered(bvh.triOrder.size());
+  for (size_t i = 0; i < ordered.size(); i++) {
+    DevTri& T = ordered[i];
+    std::memset(&T, 0, sizeof T);
+    const size_t f = (size_t)bvh.triOrder[i];
+    for (int a = 0; a < 3; a++) {
+      T.v0[a] = vertices[9 * f + a];
+      T.v1[a] = vertices[9 * f + 3 + a];
+      T.v2[a] = vertices[9 * f + 6 + a];
+      T.n[a] = normals[3 * f + a];
+    }
+    T.face = (int)f;
+  }
+  if (!addNullLeaf(ordered, wide.nodes)) return fail(RT_ERR_UNSUPPORTED, "too many triangles for the BVH leaf encoding");
+  std::vector<DevBvhNodeF> fn;
+  bool anyCone = false;
+  buildNodeCopies(wide.nodes, wide.tight, ordered, fn, anyCone);
+  const int nullTriangle = (int)ordered.size() - 1;
+  const size_t nNodes = wide.nodes.size();
+  report[0] = (long long)nNodes;
+  report[1] = wide.maxDepth;
+  report[2] = (long long)bvh.nodes.size();
+
+  // ---- the checks, written against what the traversal assumes, not against the builder
+  struct Anc { size_t node; int slot; };          // a child (slot of copy 0) on the way down to a leaf
+  std::vector<int> seen((size_t)n_tris, 0);
+  std::vector<Anc> chain;
+  // triangles below each child of copy 0, as positions in `ordered` (a contiguous run by construction; held
+  // against the walk: first, last and count)
+  struct Span { int lo = INT32_MAX, hi = -1, count = 0; };
+  std::vector<std::array<Span, 4>> spans(nNodes);
+  const auto planesOf = [&](const DevBvhNodeF& F, int j, float lo[3], float hi[3]) {
+    lo[0] = F.lo_x[j]; hi[0] = F.hi_x[j];
+    lo[1] = F.lo_y[j]; hi[1] = F.hi_y[j];
+    lo[2] = F.lo_z[j]; hi[2] = F.hi_z[j];
+  };
+  const auto leafTriangle = [&](int t) {
+    const DevTri& T = ordered[(size_t)t];
+    seen[(size_t)T.face]++;
+    const double* vs[3] = {T.v0, T.v1, T.v2};
+    const double nl = std::sqrt(T.n[0] * T.n[0] + T.n[1] * T.n[1] + T.n[2] * T.n[2]);
+    for (const Anc& an : chain) {
+      const DevBvhNodeF& F = fn[an.node * 8];
+      float lo[3], hi[3];
+      planesOf(F, an.slot, lo, hi);
+      bool outF = false, outQ = false;
+      // the quantised node's slot that holds the same child
+      const rtbvh::Node4& n4 = wide.nodes[an.node];
+      int c4 = -1;
+      for (int c = 0; c < 4; c++) if (n4.child[c] == F.child[an.slot]) c4 = c;
+      const double sc[3] = {n4.scaleX, n4.scaleY, n4.scaleZ};
+      for (int k = 0; k < 3; k++)
+        for (int a = 0; a < 3; a++) {
+          outF |= !(vs[k][a] >= (double)lo[a] && vs[k][a] <= (double)hi[a]);
+          if (c4 >= 0) {
+            const double ql = (double)n4.origin[a] + (double)((n4.qlo[a] >> (8 * c4)) & 255u) * sc[a];
+            const double qh = (double)n4.origin[a] + (double)((n4.qhi[a] >> (8 * c4)) & 255u) * sc[a];
+            outQ |= !(vs[k][a] >= ql && vs[k][a] <= qh);
+          }
+        }
+      if (outF) report[4]++;
+      if (outQ || c4 < 0) report[5]++;
+      const float* cn = F.cone[an.slot];
+      if (cn[3] < 1.0f && nl > 0.0 && std::isfinite(nl)) {
+        // every direction the cone test turns away makes an angle below 90 degrees - asin(bound) with the
+        // axis: the normal has to lie within asin(bound) of the axis
+        // (the sine from the cross product: a narrow cone's cosine says nothing)
+        const double ax = cn[0], ay = cn[1], az = cn[2];
+        const double al = std::sqrt(ax * ax + ay * ay + az * az);
+        const double cosAngle = (ax * T.n[0] + ay * T.n[1] + az * T.n[2]) / (al * nl);
+        const double cx = ay * T.n[2] - az * T.n[1], cy = az * T.n[0] - ax * T.n[2], cz = ax * T.n[1] - ay * T.n[0];
+        const double sinAngle = std::sqrt(cx * cx + cy * cy + cz * cz) / (al * nl);
+        if (!(cosAngle > 0.0 && sinAngle <= (double)cn[3])) report[6]++;
+      }
+      Span& sp = spans[an.node][(size_t)an.slot];
+      sp.lo = std::min(sp.lo, t);
+      sp.hi = std::max(sp.hi, t + 1);
+      sp.count++;
+    }
+  };
+  {
+    // depth-first over copy 0 of every node, explicit stack of (node, next slot)
+    std::vector<std::pair<size_t, int>> st{{0, 0}};
+    std::vector<char> visited(nNodes, 0);
+    visited[0] = 1;
+    while (!st.empty()) {
+      const size_t i = st.back().first;
+      const int j = st.back().second;
+      if (j == 4) {
+        st.pop_back();
+        if (!chain.empty()) chain.pop_back();
+        continue;
+      }
+      st.back().second++;
+      const DevBvhNodeF& F = fn[i * 8];
+      const int ref = F.child[j];
+      if (ref >= 0) {
+        if ((size_t)ref >= nNodes || visited[(size_t)ref]) return fail(RT_ERR_DEVICE, "child index out of range or visited twice");
+        visited[(size_t)ref] = 1;
+        chain.push_back(Anc{i, j});
+        st.push_back({(size_t)ref, 0});
+        continue;
+      }
+      const int x = ~ref, first = x >> 3, count = (x & 7) + 1;
+      float lo[3], hi[3];
+      planesOf(F, j, lo, hi);
+      if (first == nullTriangle) {
+        // an unused slot: an inverted box in both forms, so that no ray enters it
+        bool inverted = false;
+        for (int a = 0; a < 3; a++) inverted |= lo[a] > hi[a];
+        if (!inverted || count != 1) report[11]++;
+        continue;
+      }
+      if ((x & RT_BVH_OBJECT_BIT) || first < 0 || first + count > nullTriangle) return fail(RT_ERR_DEVICE, "leaf range out of bounds");
+      if (count > max_leaf) report[13]++;
+      chain.push_back(Anc{i, j});
+      for (int t = first; t < first + count; t++) leafTriangle(t);
+      chain.pop_back();
+    }
+    for (size_t i = 0; i < nNodes; i++)
+      if (!visited[i]) report[3]++;   // a node nothing points at
+  }
+  for (int f = 0; f < n_tris; f++)
+    if (seen[(size_t)f] != 1) report[3]++;
+  for (size_t i = 0; i < nNodes; i++)
+    for (int j = 0; j < 4; j++) {
+      const Span& sp = spans[i][(size_t)j];
+      if (sp.count > 0 && sp.hi - sp.lo != sp.count) report[3]++;   // not a contiguous run
+      if (fn[i * 8].cone[j][3] < 1.0f) report[12]++;
+    }
+
+  // ---- culls as the kernels take them (binary32, the visit's own expression) on directions spread around
+  // every cone's rim: whatever is turned away must hold only triangles the reference rejects one by one
+  // (trimesh.cpp:93-104: normal . direction > 0 with back faces culled)
+  {
+    unsigned long long rng = 0x9e3779b97f4a7c15ull;
+    const auto rnd = [&]() {   // uniform in [0, 1)
+      rng = rng * 6364136223846793005ull + 1442695040888963407ull;
+      return (double)(rng >> 11) * (1.0 / 9007199254740992.0);
+    };
+    const size_t step = std::max<size_t>(1, nNodes / 4096);
+    for (size_t i = 0; i < nNodes; i += step)
+      for (int j = 0; j < 4; j++) {
+        const float* cn = fn[i * 8].cone[j];
+        const Span& sp = spans[i][(size_t)j];
+        if (!(cn[3] < 1.0f) || sp.count == 0) continue;
+        // two unit vectors across the axis
+        const double A[3] = {cn[0], cn[1], cn[2]};
+        double u[3] = {0.0, 0.0, 0.0};
+        u[std::fabs(A[0]) < 0.6 ? 0 : (std::fabs(A[1]) < 0.6 ? 1 : 2)] = 1.0;
+        const double ua = u[0] * A[0] + u[1] * A[1] + u[2] * A[2];
+        for (int a = 0; a < 3; a++) u[a] -= ua * A[a];
+        const double ul = std::sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+        for (int a = 0; a < 3; a++) u[a] /= ul;
+        const double w[3] = {A[1] * u[2] - A[2] * u[1], A[2] * u[0] - A[0] * u[2], A[0] * u[1] - A[1] * u[0]};
+        for (int k = 0; k < 12; k++) {
+          // the direction's component along the axis: just above the bound (the rim, where a cull is
+          // least safe), or anywhere above it
+          const double along = (k < 8) ? std::min(1.0, (double)cn[3] * (1.0 + 1.0e-6 * k) + 1.0e-7 * k) : (double)cn[3] + (1.0 - (double)cn[3]) * rnd();
+          const double across = std::sqrt(std::max(0.0, 1.0 - along * along)), phi = 6.283185307179586 * rnd();
+          double d[3];
+          for (int a = 0; a < 3; a++) d[a] = along * A[a] + across * (std::cos(phi) * u[a] + std::sin(phi) * w[a]);
+          const double dl = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+          for (int a = 0; a < 3; a++) d[a] /= dl;
+          const float dx = (float)d[0], dy = (float)d[1], dz = (float)d[2];
+          if (!(fmaf(cn[2], dz, fmaf(cn[1], dy, cn[0] * dx)) > cn[3])) continue;   // as RT_DESCEND's cone test
+          report[8]++;
+          for (int t = sp.lo; t < sp.hi; t++) {
+            const double* nn = ordered[(size_t)t].n;
+            const double nd = nn[0] * d[0] + nn[1] * d[1] + nn[2] * d[2];
+            const double nl = std::sqrt(nn[0] * nn[0] + nn[1] * nn[1] + nn[2] * nn[2]);
+            // (a triangle without a direction is rejected by every ray: nd == 0, or NaN through every later test)
+            if (nl > 0.0 && std::isfinite(nl) && !(nd > 0.0)) { report[7]++; break; }
+          }
+        }
+      }
+  }
+
+  // ---- the eight copies of a node: the same children, reordered near to far along the copy's diagonal
+  for (size_t i = 0; i < nNodes; i++) {
+    const DevBvhNodeF& F0 = fn[i * 8];
+    for (int o = 0; o < 8; o++) {
+      const DevBvhNodeF& F = fn[i * 8 + (size_t)o];
+      bool used0[4] = {false, false, false, false};
+      bool same = true, sorted = true;
+      double lastKey = -std::numeric_limits<double>::infinity();
+      bool pastUsed = false;
+      for (int j = 0; j < 4; j++) {
+        float lo[3], hi[3];
+        planesOf(F, j, lo, hi);
+        int match = -1;
+        for (int m = 0; m < 4 && match < 0; m++) {
+          if (used0[m] || F0.child[m] != F.child[j]) continue;
+          float lo0[3], hi0[3];
+          planesOf(F0, m, lo0, hi0);
+          if (std::memcmp(lo, lo0, sizeof lo) == 0 && std::memcmp(hi, hi0, sizeof hi) == 0 &&
+              std::memcmp(F.cone[j], F0.cone[m], sizeof F.cone[j]) == 0) match = m;
+        }
+        if (match < 0) same = false; else used0[match] = true;
+        bool inverted = false;
+        double key = 0.0;
+        for (int a = 0; a < 3; a++) {
+          inverted |= lo[a] > hi[a];
+          const double centre = 0.5 * ((double)lo[a] + (double)hi[a]);
+          key += ((o >> a) & 1) ? -centre : centre;
+        }
+        if (inverted) { pastUsed = true; continue; }
+        if (pastUsed || key < lastKey) sorted = false;
+        lastKey = key;
+      }
+      if (!same) report[9]++;
+      if (!sorted) report[10]++;
+    }
+  }
   return RT_OK;
 }
 

@@ -176,6 +176,24 @@ def pow_near_int(x, n, delta):
     return out
 
 
+BVH_REPORT_FIELDS = ("nodes", "depth", "binary_nodes", "lost_triangles", "outside_f32_box", "outside_8bit_box",
+                     "normal_outside_cone", "wrong_culls", "culls_sampled", "copies_not_a_reordering",
+                     "copies_not_sorted", "bad_unused_slots", "usable_cones", "oversized_leaves")
+
+
+def bvh_invariants(vertices, normals, max_leaf=2):
+    """rt_test_bvh_invariants: the fast path's BVH over (n, 3, 3) triangle vertices with (n, 3) face normals,
+    built on the host as rt_scene_create builds it, and the counts of the invariant checks (no GPU needed)."""
+    v = np.ascontiguousarray(vertices, dtype=np.float64).reshape(-1, 9)
+    nrm = np.ascontiguousarray(normals, dtype=np.float64).reshape(-1, 3)
+    if len(v) != len(nrm):
+        raise ValueError("one normal per triangle")
+    rep = (C.c_longlong * 16)()
+    _check(lib().rt_test_bvh_invariants(len(v), v.ctypes.data_as(abi.PD), nrm.ctypes.data_as(abi.PD), max_leaf, rep),
+           "rt_test_bvh_invariants")
+    return dict(zip(BVH_REPORT_FIELDS, list(rep)))
+
+
 class MultiScene:
     """RtMulti handle: the scene on several GPUs of this node, one frame per call."""
 
