@@ -59,7 +59,8 @@ __device__ __forceinline__ V3 mul33(const double* m, const V3& v) {
 // doubles the registers of the kernel that holds it.  x^n by binary powering in
 // double-double arithmetic (products split exactly with fused multiply-adds:
 // relative error around 2^-100), times exp(delta ln x) = 1 + delta ln x, whose
-// second-order term is below 1e-18; ln x only has to be good to three digits.
+// second-order term is below 1e-18; ln x only has to be good to six digits
+// (three for the residues scenes really have, a few 1e-15).
 // The result is the correctly rounded power in practice (0 misses in 20 000
 // random cases against exact rational arithmetic, where the C library's pow
 // misses 19 by one unit in the last place).  Special cases as pow: y == 0 gives
