@@ -134,3 +134,19 @@ def test_argument_checks(built):
     for bad_leaf in (0, 9):
         with pytest.raises(Exception):
             device.bvh_invariants(v, np.zeros((1, 3)), bad_leaf)
+
+
+def test_the_benchmark_meshes(built):
+    """The structures the benchmark configurations traverse: the 1 002 528-triangle terrain of the 4K
+    configurations and the 81 922-triangle blob of the 1080p mesh configuration (closed: no cone near its root)."""
+    from raytracer_amd import scenes
+    v, f = scenes.heightfield(708, seed=4)
+    tri = np.asarray(v, dtype=np.float64)[np.asarray(f)]
+    rep = device.bvh_invariants(tri, _normals(tri), 2)
+    _clean(rep, len(tri), 2)
+    assert rep["usable_cones"] > 2 * rep["nodes"] and rep["culls_sampled"] > 50_000
+    v, f = scenes.blob_mesh(6, seed=1)
+    tri = np.asarray(v, dtype=np.float64)[np.asarray(f)]
+    rep = device.bvh_invariants(tri, _normals(tri), 2)
+    _clean(rep, len(tri), 2)
+    assert rep["usable_cones"] > 0
