@@ -1622,7 +1622,7 @@ int treeDepth(const RtSceneDesc& d, int root, int itemLimit, std::string& err) {
     const int l = d.node_left[n], r = d.node_right[n];
     if (l < 0 && r < 0) {
       const int s = d.node_item_start[n], c = d.node_item_count[n];
-      if (c < 0 || s < 0 || s + c > d.n_leaf_items) { err = "kd leaf item range out of bounds"; return -1; }
+      if (c < 0 || s < 0 || (long long)s + c > d.n_leaf_items) { err = "kd leaf item range out of bounds"; return -1; }
       for (int k = 0; k < c; k++)
         if (d.leaf_items[s + k] < 0 || d.leaf_items[s + k] >= itemLimit) {
           err = "kd leaf item out of range";
@@ -2369,6 +2369,13 @@ int rt_scene_create(const RtSceneDesc* d, RtScene** out) {
       d->n_materials < 0 || d->n_vertices < 0 || d->n_leaf_items < 0)
     return fail(RT_ERR_INVALID, "negative count in scene description");
   if (d->n_lights > 65535) return fail(RT_ERR_UNSUPPORTED, "more than 65535 lights");   // the shadow kernel's grid has one row per light
+  // an array that a count says is there has to be there
+  if ((d->n_objects > 0 && !d->objects) || (d->n_lights > 0 && !d->lights) || (d->n_meshes > 0 && !d->meshes) ||
+      (d->n_materials > 0 && !d->materials) || (d->n_vertices > 0 && !d->vertices) || (d->n_faces > 0 && !d->faces) ||
+      (d->n_leaf_items > 0 && !d->leaf_items) ||
+      (d->n_nodes > 0 && (!d->node_split || !d->node_dim || !d->node_left || !d->node_right || !d->node_item_start ||
+                          !d->node_item_count)))
+    return fail(RT_ERR_INVALID, "null array with a non-zero count in scene description");
   // ---- validate indices so that no kernel can read out of bounds
   for (int i = 0; i < d->n_objects; i++) {
     const RtObject& o = d->objects[i];
@@ -2390,8 +2397,8 @@ int rt_scene_create(const RtSceneDesc* d, RtScene** out) {
     const RtMesh& M = d->meshes[m];
     if (M.object < 0 || M.object >= d->n_objects || d->objects[M.object].mesh != m)
       return fail(RT_ERR_INVALID, "mesh/object cross reference broken");
-    if (M.first_vertex < 0 || M.n_vertices < 0 || M.first_vertex + M.n_vertices > d->n_vertices ||
-        M.first_face < 0 || M.n_faces < 0 || M.first_face + M.n_faces > d->n_faces)
+    if (M.first_vertex < 0 || M.n_vertices < 0 || (long long)M.first_vertex + M.n_vertices > d->n_vertices ||
+        M.first_face < 0 || M.n_faces < 0 || (long long)M.first_face + M.n_faces > d->n_faces)
       return fail(RT_ERR_INVALID, "mesh vertex/face range out of bounds");
     if (M.has_vertex_normals && !d->vnormals) return fail(RT_ERR_INVALID, "vertex normals missing");
     if (M.has_vertex_materials && !d->vmaterials) return fail(RT_ERR_INVALID, "vertex materials missing");
